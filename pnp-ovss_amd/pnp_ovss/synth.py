@@ -1,0 +1,139 @@
+"""Seeded synthetic weights and inputs (there is no checkpoint / dataset on the GPU box).
+
+Parameter names follow the reference's state-dict keys (module attribute paths of
+`Files to replace for BLIP/blip_image_text_matching.py`:39-57, `vit.py`:176-258, `med.py`:56-524)
+so the same dict loads into the reference modules (golden generation), the numpy oracle and the
+HIP engine.  Every tensor is drawn from its own generator seeded by (seed, crc32(name)) so any
+subset can be regenerated independently and identically anywhere.
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+from .config import ModelCfg
+
+
+def param_shapes(cfg: ModelCfg) -> "OrderedDict[str, tuple]":
+    D, H, I = cfg.vit_dim, cfg.txt_hidden, cfg.txt_inter
+    s = OrderedDict()
+    v = "visual_encoder."
+    s[v + "cls_token"] = (1, 1, D)
+    s[v + "pos_embed"] = (1, cfg.n_img_tokens, D)
+    s[v + "patch_embed.proj.weight"] = (D, 3, cfg.patch, cfg.patch)
+    s[v + "patch_embed.proj.bias"] = (D,)
+    for i in range(cfg.vit_depth):
+        b = f"{v}blocks.{i}."
+        s[b + "norm1.weight"] = (D,)
+        s[b + "norm1.bias"] = (D,)
+        s[b + "attn.qkv.weight"] = (3 * D, D)
+        s[b + "attn.qkv.bias"] = (3 * D,)
+        s[b + "attn.proj.weight"] = (D, D)
+        s[b + "attn.proj.bias"] = (D,)
+        s[b + "norm2.weight"] = (D,)
+        s[b + "norm2.bias"] = (D,)
+        s[b + "mlp.fc1.weight"] = (cfg.vit_mlp_ratio * D, D)
+        s[b + "mlp.fc1.bias"] = (cfg.vit_mlp_ratio * D,)
+        s[b + "mlp.fc2.weight"] = (D, cfg.vit_mlp_ratio * D)
+        s[b + "mlp.fc2.bias"] = (D,)
+    s[v + "norm.weight"] = (D,)
+    s[v + "norm.bias"] = (D,)
+    t = "text_encoder."
+    s[t + "embeddings.word_embeddings.weight"] = (cfg.vocab, H)
+    s[t + "embeddings.position_embeddings.weight"] = (cfg.max_pos, H)
+    s[t + "embeddings.LayerNorm.weight"] = (H,)
+    s[t + "embeddings.LayerNorm.bias"] = (H,)
+    for i in range(cfg.txt_layers):
+        b = f"{t}encoder.layer.{i}."
+        for att, kw in (("attention", H), ("crossattention", D)):
+            s[b + att + ".self.query.weight"] = (H, H)
+            s[b + att + ".self.query.bias"] = (H,)
+            s[b + att + ".self.key.weight"] = (H, kw)
+            s[b + att + ".self.key.bias"] = (H,)
+            s[b + att + ".self.value.weight"] = (H, kw)
+            s[b + att + ".self.value.bias"] = (H,)
+            s[b + att + ".output.dense.weight"] = (H, H)
+            s[b + att + ".output.dense.bias"] = (H,)
+            s[b + att + ".output.LayerNorm.weight"] = (H,)
+            s[b + att + ".output.LayerNorm.bias"] = (H,)
+        s[b + "intermediate.dense.weight"] = (I, H)
+        s[b + "intermediate.dense.bias"] = (I,)
+        s[b + "output.dense.weight"] = (H, I)
+        s[b + "output.dense.bias"] = (H,)
+        s[b + "output.LayerNorm.weight"] = (H,)
+        s[b + "output.LayerNorm.bias"] = (H,)
+    s["itm_head.weight"] = (2, H)
+    s["itm_head.bias"] = (2,)
+    return s
+
+
+def _rng(seed: int, name: str) -> np.random.Generator:
+    return np.random.default_rng([seed, zlib.crc32(name.encode())])
+
+
+def synth_tensor(name: str, shape, seed: int) -> np.ndarray:
+    """One synthetic parameter.  Scales: weights N(0, 0.02) like the reference's own init
+    (vit.py:262-269 trunc_normal 0.02; BERT normal 0.02) except attention q/k projections which are
+    widened so softmaxes are not flat; LayerNorm gains 1+N(0,0.1); every bias N(0,0.02)."""
+    g = _rng(seed, name)
+    x = g.standard_normal(size=shape, dtype=np.float32)
+    if name.endswith("LayerNorm.weight") or name.endswith("norm1.weight") or \
+            name.endswith("norm2.weight") or name.endswith("norm.weight"):
+        return (1.0 + 0.1 * x).astype(np.float32)
+    if name.endswith(".bias"):
+        return (0.02 * x).astype(np.float32)
+    if name.endswith("query.weight") or name.endswith("key.weight"):
+        return (0.06 * x).astype(np.float32)
+    if name.endswith("attn.qkv.weight"):
+        x *= 0.02
+        d = shape[1]
+        x[: 2 * d] *= 3.0          # q and k rows of the fused ViT qkv
+        return x.astype(np.float32)
+    if name == "itm_head.weight":
+        return (0.5 * x).astype(np.float32)
+    return (0.02 * x).astype(np.float32)
+
+
+def synth_state_dict(cfg: ModelCfg, seed: int = 0, names=None) -> "OrderedDict[str, np.ndarray]":
+    shapes = param_shapes(cfg)
+    out = OrderedDict()
+    for n, shp in shapes.items():
+        if names is not None and n not in names:
+            continue
+        out[n] = synth_tensor(n, shp, seed)
+    return out
+
+
+# ----------------------------------------------------------------------------- inputs
+
+CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)   # Dataset.py:434-443
+CLIP_STD = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+
+
+def synth_images(batch: int, size: int, seed: int = 1234, block: int = 8):
+    """Seeded block-smoothed uint8 RGB noise: returns
+    (rgb uint8 (B,H,W,3) used by the CRF bilateral term, normalised fp32 (B,3,H,W) network input)."""
+    g = np.random.default_rng([seed, 7])
+    nb = (size + block - 1) // block
+    coarse = g.integers(0, 256, size=(batch, nb, nb, 3), dtype=np.int64)
+    fine = g.integers(-12, 13, size=(batch, size, size, 3), dtype=np.int64)
+    rgb = np.repeat(np.repeat(coarse, block, axis=1), block, axis=2)[:, :size, :size]
+    rgb = np.clip(rgb + fine, 0, 255).astype(np.uint8)
+    x = rgb.astype(np.float32) / np.float32(255.0)
+    x = (x - CLIP_MEAN) / CLIP_STD
+    return rgb, np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
+def synth_tokens(cfg: ModelCfg, n_classes_per_image, seed: int = 1234, max_length: int = 500):
+    """Synthetic token ids `[CLS] a picture of t1..tC [SEP]` padded to `max_length`
+    (the caller's `padding="max_length", max_length=500` tokenisation at
+    PnP_OVSS_0514_updated_segmentation.py:317) with one word-piece per class."""
+    g = np.random.default_rng([seed, 11])
+    B = len(n_classes_per_image)
+    ids = np.zeros((B, max_length), dtype=np.int64)
+    lo = 110 if cfg.vocab > 400 else 3
+    for b, c in enumerate(n_classes_per_image):
+        toks = [101, lo + 1, lo + 2, lo + 3] + list(g.integers(lo + 10, cfg.vocab - 2, size=c)) + [cfg.sep_token_id]
+        ids[b, : len(toks)] = toks
+    mask = (ids != cfg.pad_token_id).astype(np.int64)
+    return ids, mask

@@ -1,0 +1,342 @@
+#!/usr/bin/env python
+"""Generate golden vectors by RUNNING THE REFERENCE ITSELF (build container only; needs
+/root/reference).  Outputs small .npz / .json fixtures next to this script; tests and the GPU box
+only ever read those fixtures.
+
+    python tests/golden/make_golden.py [--only NAME] [--skip-large]
+
+Fixtures (inputs are regenerated from seeds by pnp_ovss.synth; only outputs are stored):
+  gradcam_small.npz   compute_gradcam_ensemble, small geometry, B=2 ragged captions, all 12x12 maps
+  gradcam_large.npz   compute_gradcam_ensemble, BLIP-ITM-large 336^2, B=1, L=25: map [7][9] + logits
+  droploop_small.npz  Inference_BLIP_filteredcaption (drop_iter 4 and 1), picks per iteration
+  merge_tokens.npz    Mean_over_filtered_label_tokens on split / unsplit captions
+  pipeline_voc.npz    save_img_union_attention end to end (blur / no post-process; CRF is not
+  pipeline_psc.npz    importable here -> parity unpinned for CRF), hist .npy contents
+  gpt_parse.json      Load_predicted_classes on sampled GPT-4o strings of the shipped JSON files
+  blur_cases.npz      `blurring` (scipy gaussian_filter + min-max) incl. non-square and NaN cases
+  hist_cases.npz      _fast_hist / scores on hand-made label maps
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "pnp-ovss_amd"))
+sys.path.insert(0, HERE)
+
+from pnp_ovss import config as C            # noqa: E402
+from pnp_ovss import synth                  # noqa: E402
+from pnp_ovss.tokenizer import SynthTokenizer  # noqa: E402
+import _ref_loader as RL                    # noqa: E402
+
+torch.set_grad_enabled(True)
+
+
+def _model(cfg, seed):
+    tok = SynthTokenizer(cfg.vocab)
+    sd = synth.synth_state_dict(cfg, seed)
+    m, itm = RL.build_reference_model(cfg, sd, tok)
+    return m, itm, tok
+
+
+def gen_gradcam_small():
+    cfg = C.blip_itm_small(64)
+    m, itm, tok = _model(cfg, seed=3)
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=5)
+    caps = ["A picture of cat aeroplane dog sheep boat", "A picture of bus tvmonitor"]
+    tok500 = tok(caps, padding="max_length", max_length=500, return_tensors="pt")
+    args = argparse.Namespace(img_size=cfg.img_size)
+    g, _, out = itm.compute_gradcam_ensemble(args, m, torch.from_numpy(imgs), caps, tok500)
+    maps = np.stack([np.stack([g[l][h].numpy() for h in range(12)]) for l in range(12)])
+    layer = m.text_encoder.base_model.base_model.encoder.layer
+    P7 = layer[7].crossattention.self.get_attention_map().detach().numpy()
+    dP7 = layer[7].crossattention.self.get_attn_gradients().detach().numpy()
+    dP0 = layer[0].crossattention.self.get_attn_gradients().detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "gradcam_small.npz"),
+                        cfg=json.dumps(cfg.as_dict()), weight_seed=3, image_seed=5,
+                        captions=np.array(caps), input_ids=tok500.input_ids.numpy(),
+                        attention_mask=tok500.attention_mask.numpy(),
+                        maps=maps, logits=out.detach().numpy(), P7=P7, dP7=dP7, dP0=dP0)
+    print("gradcam_small: maps", maps.shape, "max", maps.max())
+
+
+def gen_gradcam_large():
+    cfg = C.blip_itm_large(336)
+    m, itm, tok = _model(cfg, seed=0)
+    _, imgs = synth.synth_images(1, 336, seed=1234)
+    ids, mask = synth.synth_tokens(cfg, [20], seed=1234)
+
+    class Fixed:                      # tokenizer stand-in returning the synthetic ids
+        enc_token_id = cfg.enc_token_id
+        pad_token_id = 0
+
+        def __call__(self, caps, padding="longest", max_length=None, **kw):
+            from pnp_ovss.tokenizer import Encoding
+            L = max_length if padding == "max_length" else int(mask.sum(1).max())
+            return Encoding(torch.from_numpy(ids[:, :L]), torch.from_numpy(mask[:, :L]))
+    m.tokenizer = Fixed()
+    tok500 = m.tokenizer(["x"], padding="max_length", max_length=500)
+    args = argparse.Namespace(img_size=336)
+    g, _, out = itm.compute_gradcam_ensemble(args, m, torch.from_numpy(imgs), ["x"], tok500)
+    layer = m.text_encoder.base_model.base_model.encoder.layer
+    P7 = layer[7].crossattention.self.get_attention_map().detach().numpy()
+    dP7 = layer[7].crossattention.self.get_attn_gradients().detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "gradcam_large.npz"),
+                        cfg=json.dumps(cfg.as_dict()), weight_seed=0, image_seed=1234, token_seed=1234,
+                        n_classes=20, map_7_9=g[7][9].numpy(), map_7_0=g[7][0].numpy(),
+                        map_11_3=g[11][3].numpy(), logits=out.detach().numpy(),
+                        P7_h9=P7[:, 9], dP7_h9=dP7[:, 9])
+    print("gradcam_large: map", g[7][9].shape, "max", g[7][9].max().item())
+
+
+def _driver_ns(itm, extra=None):
+    from pathlib import Path
+    import scipy.ndimage as filters
+    g = dict(torch=torch, np=np, json=json, os=os, Path=Path, filters=filters,
+             compute_gradcam_ensemble=itm.compute_gradcam_ensemble)
+    if extra:
+        g.update(extra)
+    return g
+
+
+def gen_droploop_small():
+    cfg = C.blip_itm_small(128)
+    m, itm, tok = _model(cfg, seed=4)
+    B = 3
+    _, imgs = synth.synth_images(B, cfg.img_size, seed=6)
+    caps = ["A picture of cat aeroplane dog sheep boat", "A picture of bus tvmonitor",
+            "A picture of person"]
+    img_ids = ["2007_000033", "2007_000042", "2007_000061"]
+    rec = {"zeroed": []}
+    real = itm.compute_gradcam_ensemble
+
+    def spy(args, model, visual_input, text_input, tokenized_text, drop_iter=0):
+        x = visual_input.detach().numpy()
+        P = cfg.grid
+        blk = x.reshape(x.shape[0], 3, P, 16, P, 16)
+        rec["zeroed"].append((np.abs(blk).sum(axis=(1, 3, 5)) == 0).reshape(x.shape[0], -1))
+        return real(args, model, visual_input, text_input, tokenized_text, drop_iter)
+    ns = RL.load_driver_functions(["Inference_BLIP_filteredcaption"], _driver_ns(itm))
+    ns["compute_gradcam_ensemble"] = spy
+    out = {}
+    for di in (4, 1):
+        rec["zeroed"] = []
+        args = argparse.Namespace(img_size=cfg.img_size, drop_iter=di, max_att_block_num=8,
+                                  prune_att_head="9", del_patch_num="sort_thresh005")
+        tok500 = tok(caps, padding="max_length", max_length=500, return_tensors="pt")
+        norm_imgs = torch.zeros(B, cfg.img_size, cfg.img_size, 3)
+        g0, agg = ns["Inference_BLIP_filteredcaption"](args, RL.DDPLike(m), tok500, torch.from_numpy(imgs.copy()),
+                                                       norm_imgs, img_ids, caps, [c.split()[3:] for c in caps], "cpu")
+        out[f"g0_d{di}"] = g0.numpy()
+        if agg is not None:
+            out[f"agg_d{di}"] = agg.numpy()
+        out[f"zeroed_d{di}"] = np.stack(rec["zeroed"])
+    tok500 = tok(caps, padding="max_length", max_length=500, return_tensors="pt")
+    np.savez_compressed(os.path.join(HERE, "droploop_small.npz"), cfg=json.dumps(cfg.as_dict()),
+                        weight_seed=4, image_seed=6, captions=np.array(caps),
+                        input_ids=tok500.input_ids.numpy(), attention_mask=tok500.attention_mask.numpy(), **out)
+    print("droploop_small:", {k: v.shape for k, v in out.items()})
+
+
+def gen_merge_tokens():
+    tok = SynthTokenizer(1024)
+    ns = RL.load_driver_functions(["Mean_over_filtered_label_tokens"], dict(torch=torch, np=np))
+
+    class M:
+        tokenizer = tok
+    caps = ["A picture of cat pottedplant dog",              # split word in the middle
+            "A picture of cat dog tvmonitor",                 # split word last (summed, not averaged)
+            "A picture of aeroplane",                         # single split word
+            "A picture of cat dog bus",                       # no split: fast path
+            "A picture of diningtable pottedplant"]           # two split words in a row
+    classes = [c.split()[3:] for c in caps]
+    tk = tok(caps, padding="max_length", max_length=500, return_tensors="pt")
+    Lmax = int(tk.attention_mask.sum(1).max())
+    g = torch.Generator().manual_seed(0)
+    maps = torch.rand(len(caps), Lmax - 1, 5, 5, generator=g)
+    out = {}
+    for i in range(len(caps)):
+        r = ns["Mean_over_filtered_label_tokens"](RL.DDPLike(M), tk, maps[i], classes, i)
+        out[f"merged_{i}"] = r.numpy()
+    pieces = [[tok.decode([t]) for t in tk.input_ids[i][: int(tk.attention_mask[i].sum())]] for i in range(len(caps))]
+    np.savez_compressed(os.path.join(HERE, "merge_tokens.npz"), captions=np.array(caps),
+                        input_ids=tk.input_ids.numpy(), attention_mask=tk.attention_mask.numpy(),
+                        maps=maps.numpy(), pieces=json.dumps(pieces), **out)
+    print("merge_tokens:", {k: v.shape for k, v in out.items()})
+
+
+def _psc_cats():
+    import ast as _ast
+    tree = _ast.parse(open(RL.REF + "/Load_datasets.py").read())
+    for fn in tree.body:
+        if isinstance(fn, _ast.FunctionDef) and fn.name == "load_psc":
+            for node in _ast.walk(fn):
+                if isinstance(node, _ast.Assign) and getattr(node.targets[0], "id", "") == "cats":
+                    return _ast.literal_eval(node.value)
+
+
+VOC_CATS = {1: "aeroplane", 2: "bicycle", 3: "bird", 4: "boat", 5: "bottle", 6: "bus", 7: "car", 8: "cat",
+            9: "chair", 10: "cow", 11: "table", 12: "dog", 13: "horse", 14: "motorbike", 15: "person",
+            16: "pottedplant", 17: "sheep", 18: "sofa", 19: "train", 20: "tvmonitor"}
+
+
+def _gen_pipeline(data_type, img_ids, cats, fname):
+    """save_img_union_attention end to end on 3 synthetic images of different original sizes
+    (GPT-4o class strings are the reference's shipped JSON for the chosen ids)."""
+    cfg = C.blip_itm_small(128)
+    m, itm, tok = _model(cfg, seed=4)
+    B = 3
+    _, imgs = synth.synth_images(B, cfg.img_size, seed=6)
+    sizes = [(90, 120), (128, 128), (75, 100)]   # H+W > 128: torch generic bilinear kernel
+    rng = np.random.default_rng(99)
+    org = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    gts = [rng.integers(0, len(cats) + 1, size=(h, w)).astype(np.float32) for h, w in sizes]
+    nms = list(cats.values())
+    names = ["save_img_union_attention", "Inference_BLIP_filteredcaption", "Load_predicted_classes",
+             "Mean_over_filtered_label_tokens", "postprocess", "blurring", "Scale_0_1", "_fast_hist", "scores"]
+    ns = RL.load_driver_functions(names, _driver_ns(itm))
+    ns["load_OrgImage"] = lambda args, ids: org
+    ns["Load_GroundTruth"] = lambda args, ids: gts
+    out = {}
+    real_sc = ns["scores"]
+    for pp in ("blur", None):
+        rec, labs = [], []
+        real_pp = ns["postprocess"]
+        if pp:
+            def spy(args, pred, org_img_list, label_trues, img, _r=rec, _f=real_pp):
+                _r.append(pred.detach().clone().numpy().astype(np.float32))
+                return _f(args, pred, org_img_list, label_trues, img)
+            ns["postprocess"] = spy
+
+        def spy_scores(lt, lp, cats_, n_class, _l=labs):
+            _l.append([np.array(x).astype(np.uint8) for x in lp])     # final (remapped) label maps
+            return real_sc(lt, lp, cats_, n_class)
+        ns["scores"] = spy_scores
+        tmp = tempfile.mkdtemp()
+        args = argparse.Namespace(img_size=cfg.img_size, drop_iter=4, max_att_block_num=8, prune_att_head="9",
+                                  del_patch_num="sort_thresh005", data_type=data_type, postprocess=pp,
+                                  threshold=0.15, home_dir=RL.REF, save_path=tmp)
+        tok500 = tok(["x"] * B, padding="max_length", max_length=500, return_tensors="pt")
+        norm_imgs = torch.zeros(B, cfg.img_size, cfg.img_size, 3)
+        with np.errstate(all="ignore"):
+            ns["save_img_union_attention"](RL.DDPLike(m), torch.from_numpy(imgs.copy()), None, args, None, img_ids,
+                                           4, norm_imgs, None, cats, nms, tok500, "cpu", att_head=9, max_block_num=8)
+        ns["postprocess"] = real_pp
+        ns["scores"] = real_sc
+        tag = pp or "none"
+        for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
+            f = os.path.join(tmp, d, f"img_{img_ids[0]}_max_blocknum_8_atthead_9.npy")
+            out[f"{d}_{tag}"] = np.load(f)
+        for i, r in enumerate(rec):
+            out[f"prepost_{tag}_{i}"] = r          # order: 1-drop imgs 0..B-1 then N-drop imgs 0..B-1
+        for br, name in enumerate(("1drop", "ndrop")):
+            for i in range(B):
+                out[f"labels_{name}_{tag}_{i}"] = labs[br][i]
+    gpt = json.load(open(RL.REF + f"/GPT4o_classification/{data_type}_classification_noboundary.json"))
+    np.savez_compressed(os.path.join(HERE, fname), cfg=json.dumps(cfg.as_dict()), weight_seed=4,
+                        image_seed=6, img_ids=np.array(img_ids), gpt=json.dumps({k: gpt[k] for k in img_ids}),
+                        cats=json.dumps(cats), data_type=data_type, sizes=np.array(sizes), org_seed=99, **out)
+    print(fname, {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def gen_pipeline_voc():
+    _gen_pipeline("voc", ["2007_008374", "2007_000129", "2007_009419"], VOC_CATS, "pipeline_voc.npz")
+
+
+def gen_pipeline_psc():
+    _gen_pipeline("psc", ["2008_000009", "2008_000003", "2008_000032"], _psc_cats(), "pipeline_psc.npz")
+
+
+def gen_gpt_parse():
+    ns = RL.load_driver_functions(["Load_predicted_classes"], dict(json=json))
+    res = {}
+    root = RL.REF + "/GPT4o_classification/"
+    tables = {
+        "voc": ["aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "table", "dog",
+                "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor"],
+    }
+    # nms tables for psc / ade20k come from the reference loaders (Load_datasets.py) at generation time
+    import ast as _ast
+    src = open(RL.REF + "/Load_datasets.py").read()
+    tree = _ast.parse(src)
+    for fn in tree.body:
+        if isinstance(fn, _ast.FunctionDef) and fn.name == "load_psc":
+            for node in _ast.walk(fn):
+                if isinstance(node, _ast.Assign) and getattr(node.targets[0], "id", "") == "cats":
+                    tables["psc"] = list(_ast.literal_eval(node.value).values())
+    for dt in ("voc", "psc"):
+        data = json.load(open(f"{root}{dt}_classification_noboundary.json"))
+        keys = sorted(data.keys())
+        step = max(1, len(keys) // 60)
+        pick = keys[::step][:60]
+        # add odd-looking strings explicitly
+        odd = [k for k in keys if ("\n" in data[k] or data[k] == "" or "%" not in data[k])][:15]
+        pick = sorted(set(pick + odd))
+        nms = tables[dt]
+        exp = {}
+        for k in pick:
+            args = argparse.Namespace(home_dir=RL.REF, data_type=dt)
+            try:
+                b, c, cap = ns["Load_predicted_classes"](args, nms, [], [], [], None, [k], 0, pred_path=None)
+                exp[k] = {"raw": data[k], "best_class_idx": b[0], "classes": c[0], "caption": cap[0]}
+            except Exception as e:          # the reference raises on some malformed strings: record that
+                exp[k] = {"raw": data[k], "error": type(e).__name__}
+        res[dt] = {"nms": nms, "cases": exp}
+    json.dump(res, open(os.path.join(HERE, "gpt_parse.json"), "w"), indent=0)
+    print("gpt_parse:", {k: len(v["cases"]) for k, v in res.items()})
+
+
+def gen_blur_cases():
+    import scipy.ndimage as filters
+    ns = RL.load_driver_functions(["blurring"], dict(filters=filters, np=np, torch=torch))
+    rng = np.random.default_rng(5)
+    out = {}
+    for i, (h, w) in enumerate([(64, 64), (75, 100), (33, 21), (336, 336)]):
+        x = rng.random((h, w), dtype=np.float32)
+        x[x < 0.6] = 0
+        out[f"in_{i}"] = x
+        out[f"out_{i}"] = ns["blurring"](torch.from_numpy(x), (h, w), scale=0.05)
+    z = np.zeros((40, 30), dtype=np.float32)
+    out["in_nan"] = z
+    with np.errstate(all="ignore"):
+        out["out_nan"] = ns["blurring"](torch.from_numpy(z), (40, 30), scale=0.05)
+    np.savez_compressed(os.path.join(HERE, "blur_cases.npz"), **out)
+    print("blur_cases ok; nan case all-nan:", bool(np.isnan(out["out_nan"]).all()))
+
+
+def gen_hist_cases():
+    ns = RL.load_driver_functions(["_fast_hist", "scores"], dict(np=np))
+    rng = np.random.default_rng(8)
+    cats = {i: f"c{i}" for i in range(1, 21)}
+    lt = [rng.integers(0, 21, size=(30, 40)).astype(np.float32), rng.integers(0, 21, size=(17, 9)).astype(np.float32)]
+    lp = [rng.integers(0, 21, size=(30, 40)).astype(np.float32), rng.integers(0, 21, size=(17, 9)).astype(np.float32)]
+    lt[1][0, :] = 255            # out-of-range gt is ignored by the mask
+    with np.errstate(all="ignore"):
+        acc, hist = ns["scores"](lt, lp, cats, n_class=21)
+    np.savez_compressed(os.path.join(HERE, "hist_cases.npz"), lt0=lt[0], lt1=lt[1], lp0=lp[0], lp1=lp[1], hist=hist,
+                        miou=acc["Mean IoU"], pixacc=acc["Pixel Accuracy"], fwiou=acc["Frequency Weighted IoU"],
+                        macc=acc["Mean Accuracy"])
+    print("hist_cases: mIoU", acc["Mean IoU"])
+
+
+GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, droploop_small=gen_droploop_small,
+            merge_tokens=gen_merge_tokens, pipeline_voc=gen_pipeline_voc, pipeline_psc=gen_pipeline_psc, gpt_parse=gen_gpt_parse,
+            blur_cases=gen_blur_cases, hist_cases=gen_hist_cases)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--skip-large", action="store_true")
+    a = ap.parse_args()
+    for name, fn in GENS.items():
+        if a.only and name != a.only:
+            continue
+        if a.skip_large and name == "gradcam_large":
+            continue
+        fn()

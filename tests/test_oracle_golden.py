@@ -1,0 +1,198 @@
+"""CPU: the oracle (numpy/C restatement) against golden vectors produced by the reference itself."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from pnp_ovss import config as C, synth
+from pnp_ovss.tokenizer import SynthTokenizer
+from oracle import blip_itm_np as OM
+from oracle import pipeline_np as OP
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _cfg(g):
+    return C.ModelCfg(**json.loads(str(g["cfg"])))
+
+
+def test_gradcam_small_all_layers(golden_dir):
+    g = _load(golden_dir, "gradcam_small.npz")
+    cfg = _cfg(g)
+    W = synth.synth_state_dict(cfg, int(g["weight_seed"]))
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=int(g["image_seed"]))
+    maps, logits, raw = OM.compute_gradcam(W, cfg, imgs, g["input_ids"], g["attention_mask"])
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(raw[7][0], g["P7"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(raw[7][1], g["dP7"], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(raw[0][1], g["dP0"], rtol=0, atol=5e-5)
+    ours = np.stack([maps[l] for l in range(12)])            # (layer,B,head,...)
+    ref = g["maps"].transpose(0, 2, 1, 3, 4, 5)              # (layer,head,B,..) -> (layer,B,head,..)
+    np.testing.assert_allclose(ours, ref, rtol=0, atol=1e-5)  # north_star: 1e-4 max-abs
+    # relative check after the pipeline's own per-map min-max (SURVEY §7 "Tolerance definition")
+    sel_o, sel_r = ours[7][:, 9], ref[7][:, 9]
+    for b in range(2):
+        for t in range(sel_r.shape[1]):
+            r = sel_r[b, t]
+            if r.max() > r.min():
+                a = (sel_o[b, t] - sel_o[b, t].min()) / (sel_o[b, t].max() - sel_o[b, t].min())
+                rr = (r - r.min()) / (r.max() - r.min())
+                assert np.abs(a - rr).max() < 1e-4
+
+
+@pytest.mark.slow
+def test_gradcam_large_selected_head(golden_dir):
+    g = _load(golden_dir, "gradcam_large.npz")
+    cfg = _cfg(g)
+    W = synth.synth_state_dict(cfg, int(g["weight_seed"]))
+    _, imgs = synth.synth_images(1, 336, seed=int(g["image_seed"]))
+    ids, mask = synth.synth_tokens(cfg, [int(g["n_classes"])], seed=int(g["token_seed"]))
+    maps, logits, raw = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7, 11])
+    np.testing.assert_allclose(logits, g["logits"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(maps[7][:, 9], g["map_7_9"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(maps[7][:, 0], g["map_7_0"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(maps[11][:, 3], g["map_11_3"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(raw[7][0][:, 9], g["P7_h9"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(raw[7][1][:, 9], g["dP7_h9"], rtol=0, atol=1e-4)
+
+
+def test_drop_loop(golden_dir):
+    g = _load(golden_dir, "droploop_small.npz")
+    cfg = _cfg(g)
+    W = synth.synth_state_dict(cfg, int(g["weight_seed"]))
+    _, imgs = synth.synth_images(3, cfg.img_size, seed=int(g["image_seed"]))
+    g0, agg, picks = OP.drop_loop(W, cfg, imgs, g["input_ids"], g["attention_mask"], 4, 7, 9)
+    np.testing.assert_allclose(g0, g["g0_d4"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(agg, g["agg_d4"], rtol=0, atol=5e-5)
+    # the patches zeroed in the image at iteration k are exactly the picks of iterations < k
+    zeroed = g["zeroed_d4"]                                   # (iter, B, P*P) bool
+    acc = [set() for _ in range(3)]
+    for it in range(4):
+        for b in range(3):
+            assert set(np.nonzero(zeroed[it, b])[0]) == acc[b], (it, b)
+            acc[b] |= set(picks[it][b])
+    g0_1, agg_1, _ = OP.drop_loop(W, cfg, imgs, g["input_ids"], g["attention_mask"], 1, 7, 9)
+    assert agg_1 is None
+    np.testing.assert_allclose(g0_1, g["g0_d1"], rtol=0, atol=1e-5)
+
+
+def test_merge_tokens(golden_dir):
+    g = _load(golden_dir, "merge_tokens.npz")
+    pieces = json.loads(str(g["pieces"]))
+    caps = [str(c) for c in g["captions"]]
+    for i, cap in enumerate(caps):
+        n_cls = len(cap.split()[3:])
+        pc = pieces[i][4:-1]                                  # drop [CLS] a picture of ... [SEP]
+        out = OP.merge_tokens(g["maps"][i], pc, n_cls)
+        np.testing.assert_array_equal(out, g[f"merged_{i}"])
+
+
+def test_gpt_parse(golden_dir):
+    data = json.load(open(os.path.join(golden_dir, "gpt_parse.json")))
+    n = 0
+    for dt, d in data.items():
+        for k, case in d["cases"].items():
+            if "error" in case:
+                with pytest.raises(Exception):
+                    OP.parse_gpt_classes(case["raw"], d["nms"])
+                continue
+            best, names, cap = OP.parse_gpt_classes(case["raw"], d["nms"])
+            assert best == case["best_class_idx"] and names == case["classes"] and cap == case["caption"], k
+            n += 1
+    assert n > 100
+
+
+def test_blur_matches_reference_bit_exact(golden_dir):
+    g = _load(golden_dir, "blur_cases.npz")
+    for i in range(4):
+        x = g[f"in_{i}"]
+        out = OP.blurring(x, x.shape)
+        np.testing.assert_array_equal(out, g[f"out_{i}"])
+    assert np.isnan(OP.blurring(g["in_nan"], g["in_nan"].shape)).all()
+    assert np.isnan(g["out_nan"]).all()
+
+
+def test_hist_scores(golden_dir):
+    g = _load(golden_dir, "hist_cases.npz")
+    acc, hist = OP.scores([g["lt0"], g["lt1"]], [g["lp0"], g["lp1"]], 21)
+    np.testing.assert_array_equal(hist, g["hist"])
+    assert acc["Mean IoU"] == float(g["miou"])
+    assert acc["Pixel Accuracy"] == float(g["pixacc"])
+    assert acc["Frequency Weighted IoU"] == float(g["fwiou"])
+
+
+@pytest.mark.parametrize("fname", ["pipeline_voc.npz", "pipeline_psc.npz"])
+def test_pipeline_end_to_end(golden_dir, fname):
+    """save_img_union_attention restated (oracle.segment_batch) vs the reference run:
+    pre-post-process maps bit-exact given the reference's maps is not available here, so compare
+    through the model: maps within float tolerance, histograms identical."""
+    g = _load(golden_dir, fname)
+    cfg = _cfg(g)
+    data_type = str(g["data_type"])
+    cats = {int(k): v for k, v in json.loads(str(g["cats"])).items()}
+    nms = list(cats.values())
+    W = synth.synth_state_dict(cfg, int(g["weight_seed"]))
+    B = 3
+    _, imgs = synth.synth_images(B, cfg.img_size, seed=int(g["image_seed"]))
+    sizes = [tuple(int(v) for v in s) for s in g["sizes"]]
+    rng = np.random.default_rng(int(g["org_seed"]))
+    org = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    gts = [rng.integers(0, len(cats) + 1, size=(h, w)).astype(np.float32) for h, w in sizes]
+    gpt = json.loads(str(g["gpt"]))
+    tok = SynthTokenizer(cfg.vocab)
+    best, caps = [], []
+    for k in [str(s) for s in g["img_ids"]]:
+        b, names, cap = OP.parse_gpt_classes(gpt[k], nms)
+        best.append(b)
+        caps.append(cap)
+    enc = tok(caps, padding="max_length", max_length=500)
+    ids, mask = enc.input_ids.numpy(), enc.attention_mask.numpy()
+    pieces = [[tok.decode([t]) for t in ids[i][4:int(mask[i].sum()) - 1]] for i in range(B)]
+    for mode in ("blur", None):
+        l1, ln, aux = OP.segment_batch(W, cfg, imgs, ids, mask, pieces, best, org, sizes, data_type=data_type,
+                                       mode=mode)
+        tag = mode or "none"
+        for br, (name, labs) in enumerate((("1drop", l1), ("ndrop", ln))):
+            for i in range(B):
+                ref_lab = g[f"labels_{name}_{tag}_{i}"].astype(np.float32)
+                bg = OP.has_background(data_type, len(best[i]))
+                if mode:
+                    ref_pre = g[f"prepost_{tag}_{br * B + i}"]
+                    ours_pre = aux["pre"]["1" if br == 0 else "n"][i]
+                    np.testing.assert_allclose(ours_pre, ref_pre, rtol=0, atol=2e-5 if br == 0 else 1e-4)
+                    # stage parity: the reference's own pre-post maps through the oracle's
+                    # blur + argmax + remap must reproduce the reference's labels bit-exactly
+                    stage = OP.remap_labels(OP.postprocess(mode, ref_pre, org[i], sizes[i]), best[i], bg)
+                    np.testing.assert_array_equal(stage, ref_lab)
+                # end to end through the oracle's own model: only near-tie pixels may flip
+                # (maps agree to ~1e-6; two channels within 1e-4 relative at a pixel is a tie)
+                pre = aux["pre"]["1" if br == 0 else "n"][i]
+                if mode:
+                    pre = np.stack([OP.blurring(pre[c], sizes[i]) for c in range(pre.shape[0])])
+                srt = np.sort(pre, axis=0)
+                tie = (srt[-1] - srt[-2]) <= 1e-4 * np.abs(srt[-1]) if pre.shape[0] > 1 else np.zeros(sizes[i], bool)
+                bad = (labs[i] != ref_lab) & ~tie
+                assert bad.sum() == 0, (mode, name, i, int(bad.sum()))
+
+
+def test_upsample_matches_torch_generic_kernel():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(0)
+    for (P, H, W, Cn) in [(21, 336, 336, 20), (8, 90, 120, 4), (21, 375, 500, 2), (48, 512, 683, 5)]:
+        x = rng.random((Cn, P, P), dtype=np.float32)
+        x[x < 0.5] = 0
+        ref = torch.nn.functional.interpolate(torch.from_numpy(x)[None], size=(H, W), mode="bilinear",
+                                              align_corners=True)[0].numpy()
+        np.testing.assert_array_equal(OP.bilinear_align_corners(x, H, W), ref)
+
+
+def test_blur_matches_scipy_directly():
+    import scipy.ndimage as ndi
+    rng = np.random.default_rng(3)
+    for (h, w) in [(50, 70), (336, 336), (20, 500)]:
+        x = rng.random((h, w), dtype=np.float32)
+        sig = 0.05 * max(h, w)
+        np.testing.assert_array_equal(OP.gaussian_blur(x, sig), ndi.gaussian_filter(x, sig))
