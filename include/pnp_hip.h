@@ -1,0 +1,154 @@
+/* pnp_hip.h -- C ABI of libpnp_hip.so, the MI355X (gfx950) engine behind the PnP-OVSS hot path.
+ *
+ * The reference (letitiabanana/PnP-OVSS) is pure Python and has NO native boundary of its own; the
+ * closest analogue is pydensecrf's DenseCRF2D object (PnP_OVSS_0514_updated_segmentation.py:
+ * 1066-1071).  Each entry point below therefore cites the reference *Python* interface it replaces
+ * (PnP.py = PnP_OVSS_0514_updated_segmentation.py, B/ = "Files to replace for BLIP/").
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types; every call returns 0 or a negative
+ *     errno-style code, message via pnp_last_error(); no exception crosses the boundary.
+ *   - "d_" pointers are DEVICE pointers owned by the caller (e.g. torch tensor .data_ptr()),
+ *     contiguous row-major; `stream` is a hipStream_t (NULL = default stream).
+ *   - All device memory the engine needs is allocated in pnp_create / pnp_post_reserve; the hot
+ *     path calls allocate nothing and never synchronise the device (hipGraph-capturable) except
+ *     where stated.
+ *   - One engine per device per process; an engine is not thread-safe; engines are independent
+ *     (matches the one-process-per-GPU model of PnP.py:1439).
+ */
+#ifndef PNP_HIP_H
+#define PNP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pnp_engine pnp_engine;
+
+/* Geometry of `load_model_and_preprocess("blip_image_text_matching", "large")`
+ * (B/blip_itm_large.yaml, B/vit.py:511-523, LAVIS med_large_config.json). */
+typedef struct pnp_config {
+    int32_t img_size, patch, vit_dim, vit_depth, vit_heads, vit_mlp_ratio;
+    float vit_ln_eps;
+    int32_t txt_hidden, txt_layers, txt_heads, txt_inter;
+    float txt_ln_eps;
+    int32_t vocab, max_pos, enc_token_id;
+    int32_t max_batch;      /* images per step (--batch_size, PnP.py:58) */
+    int32_t max_text_len;   /* longest tokenised caption the engine must hold (<= 192) */
+    int32_t stash_layer;    /* args.max_att_block_num - 1 (PnP.py:619): text layer whose P and dL/dP are kept */
+    int32_t compute_bf16;   /* 1: bf16 storage + fp32 accumulate MFMA; 0: exact fp32 MFMA (parity mode) */
+    int32_t device;         /* HIP device ordinal */
+} pnp_config;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int pnp_create(const pnp_config* cfg, pnp_engine** out);
+void pnp_destroy(pnp_engine* e);
+const char* pnp_last_error(const pnp_engine* e);          /* valid until the next call on e */
+size_t pnp_workspace_bytes(const pnp_config* cfg);         /* device bytes pnp_create will allocate */
+
+/* Weights in: replaces BaseModel.load_checkpoint + load_state_dict (B/base_model.py:86-125).
+ * `name` is the reference state-dict key ("visual_encoder.blocks.3.attn.qkv.weight", ...), data is
+ * fp32 (host pointer, or device pointer when on_device != 0, e.g. after an RCCL broadcast).
+ * Unknown names are ignored (strict=False), shape mismatches are errors. */
+int pnp_load_weight(pnp_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim,
+                    int32_t on_device);
+/* Builds fused / transposed device copies; fails with the first missing tensor name. Synchronises. */
+int pnp_finalize_weights(pnp_engine* e);
+
+/* ---- model: replaces BlipITM.forward(match_head="itm") + loss.backward() + hooks -------- */
+/* VisionTransformer.forward (B/vit.py:274-290).  d_images: (B,3,S,S) fp32 normalised.
+ * d_dropped: optional (B, P*P) uint8, 1 = patch zeroed by the salience drop (PnP.py:597-603). */
+int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream);
+/* BertModel.forward(mode="multimodal") + itm_head (B/med.py:854-1024, B/blip_image_text_matching.py:
+ * 238-249); stashes the cross-attention probabilities of layers >= stash_layer (B/med.py:280-283).
+ * d_ids / d_mask: (B, ld) int64, the first L columns are used (padding="longest"). */
+int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const int64_t* d_mask, int32_t ld, int32_t B,
+                           int32_t L, float* d_logits, void* stream);
+/* loss = logits[:,1].sum(); loss.backward() restricted to what reaches attention_probs of
+ * stash_layer (B/blip_image_text_matching.py:399-404, hook B/med.py:164-168). */
+int pnp_xattn_grad(pnp_engine* e, int32_t B, int32_t L, void* stream);
+/* cams * relu(grads) * mask for one head, [ENC] row and image-CLS column dropped
+ * (B/blip_image_text_matching.py:427-433).  d_out: (B, L-1, P, P) fp32. */
+int pnp_gradcam_gather(pnp_engine* e, const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t head,
+                       float* d_out, void* stream);
+/* compute_gradcam_ensemble for [stash_layer][head] (B/blip_image_text_matching.py:386-457). */
+int pnp_compute_gradcam(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
+                        const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t head, float* d_out,
+                        float* d_logits, void* stream);
+
+/* ---- salience-drop loop: replaces Inference_BLIP_filteredcaption (PnP.py:564-722) -------- */
+/* One bookkeeping step (PnP.py:619-647 + the running sum of :716-721) on a gathered map. */
+int pnp_drop_step(pnp_engine* e, const float* d_gradcam, float* d_g0, float* d_agg, uint8_t* d_dropped,
+                  int32_t* d_picks, int32_t iter, int32_t B, int32_t T, int32_t npick, int32_t max_picks,
+                  void* stream);
+/* The whole loop, device resident, no host sync.  d_g0 / d_agg: (B, L-1, P, P); d_picks: (B, drop_iter*npick)
+ * int32 patch ids in pick order; drop_iter == 1 -> single forward, d_agg untouched. */
+int pnp_drop_loop(pnp_engine* e, const float* d_images, const int64_t* d_ids, const int64_t* d_mask, int32_t ld,
+                  int32_t B, int32_t L, int32_t head, int32_t drop_iter, int32_t npick, float* d_g0, float* d_agg,
+                  int32_t* d_picks, float* d_logits, void* stream);
+
+/* ---- post-process: replaces PnP.py:348-403 / 424-481 + postprocess/densecrf/scores ------ */
+typedef struct pnp_post_batch {
+    int32_t B;
+    const int32_t* H;            /* [B] original image height (label_trues[img].shape[0]) */
+    const int32_t* W;            /* [B] */
+    const int32_t* n_classes;    /* [B] selected classes (len(best_class_idx_list[img])) */
+    const int32_t* has_bg;       /* [B] background channel prepended (PnP.py:373-379) */
+    /* Mean_over_filtered_label_tokens plan (PnP.py:810-853): class c of image b sums tokens
+     * tok_idx[cls_off[img_cls_off[b]+c] .. cls_off[img_cls_off[b]+c+1]) (indices into map[3:-1]),
+     * then divides by cls_div when != 1 */
+    const int32_t* img_cls_off;  /* [B+1] */
+    const int32_t* cls_off;      /* [total_classes+1] */
+    const int32_t* tok_idx;      /* [total_tokens] */
+    const int32_t* cls_div;      /* [total_classes] */
+    const int32_t* lut;          /* [B*lut_stride] argmax index -> dataset class id (PnP.py:390-399 folded) */
+    int32_t lut_stride;
+    const uint8_t* d_rgb;        /* device: concatenated original RGB images (sum H*W*3), CRF bilateral */
+    const float* d_gt;           /* device: concatenated ground-truth label maps (sum H*W) or NULL */
+    /* optional host-provided Gaussian taps (float64), image b uses blur_wts[blur_wt_off[b] + j] for
+     * distance j = 0..radius, radius = blur_wt_off[b+1] - blur_wt_off[b] - 1.  NULL: computed by the
+     * engine as scipy's _gaussian_kernel1d(0.05 * max(H, W), truncate 4).  The Python host passes
+     * numpy-computed taps so the blur is bit-identical to scipy.ndimage.gaussian_filter. */
+    const double* blur_wts;
+    const int32_t* blur_wt_off;  /* [B+1] */
+} pnp_post_batch;
+
+/* Reserve device memory for post-processing batches up to these bounds (call once; allocates). */
+int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_total_pixels, int32_t max_pixels_per_image,
+                     int32_t max_channels, int32_t crf_chunk);
+/* Upload descriptors/plan of a batch, compute blur taps, and (when want_crf) build both
+ * permutohedral lattices + normalisers for its images.  Synchronises once (range check). */
+int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* batch, int32_t want_crf, void* stream);
+/* Stage calls operate on the prepared batch and the engine's internal map buffers. */
+int pnp_merge_tokens(pnp_engine* e, const float* d_gradcam, int32_t T, void* stream);          /* PnP.py:810-853 */
+int pnp_threshold_upsample(pnp_engine* e, float threshold, int32_t scale01, void* stream);      /* PnP.py:348-379 */
+int pnp_blur_minmax(pnp_engine* e, void* stream);                                               /* PnP.py:1149-1153 */
+int pnp_densecrf(pnp_engine* e, int32_t iters, float pos_w, float pos_xy, float bi_w, float bi_xy, float bi_rgb,
+                 void* stream);                                                                  /* PnP.py:1030-1074 */
+/* argmax (+CRF marginals when from_crf) -> remap -> uint8 labels (concatenated, sum H*W) and, when
+ * d_gt was given, hist[n_class*gt + pred] += 1 (PnP.py:1106-1146). d_hist: n_class*n_class uint64. */
+int pnp_remap_hist(pnp_engine* e, int32_t from_crf, uint8_t* d_labels, unsigned long long* d_hist, int32_t n_class,
+                   void* stream);
+/* merge -> threshold/upsample -> [blur] -> [crf] -> argmax/remap/hist.  mode: bit0 blur, bit1 crf. */
+int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T, float threshold, int32_t scale01, int32_t mode,
+                    uint8_t* d_labels, unsigned long long* d_hist, int32_t n_class, void* stream);
+
+/* ---- introspection (tests / profiling) --------------------------------------------------- */
+/* Named internal device buffers: "image_embeds" (fp32 B*N*D), "maps" (fp32 post-process maps),
+ * "crf_q", "P", "dP", "crf_M" (int32 [2][B+1] lattice id bases), ... */
+int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, size_t* bytes);
+/* Stand-alone operator entry points used by the parity tests (device pointers, see csrc/). */
+int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,
+                const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, int32_t gelu,
+                void* stream);
+int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
+                     float* d_y, void* stream);
+int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PNP_HIP_H */

@@ -72,11 +72,13 @@ def zero_patches(imgs, picks, grid, patch=16):
 
 
 def select_topk(sal, picked, k=10):
-    """PnP.py:638-647: previously picked cells -> 0, then the k largest (np.argsort, ascending)."""
+    """PnP.py:638-647: previously picked cells -> 0, then the k largest (np.argsort, ascending).
+    The reference's default quicksort leaves ties (only ever among exact zeros) implementation
+    defined; the build fixes them as a stable ascending sort (larger index wins the tail)."""
     s = sal.flatten().copy()
     for p in picked:
         s[p] = 0
-    return [int(i) for i in np.argsort(s)[-k:]]
+    return [int(i) for i in np.argsort(s, kind="stable")[-k:]]
 
 
 def drop_loop(W, cfg, imgs, ids500, mask500, drop_iter, layer, head, gradcam_fn=None):

@@ -1,0 +1,1141 @@
+// The engine behind include/pnp_hip.h: owns weights + workspace on one MI355X, sequences the
+// hand-written kernels of this directory on the caller's stream.  Host logic only; every FLOP and
+// byte of the hot path is in the .hip kernels.  No allocation / sync inside hot-path calls.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pnp_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+using namespace pnp;
+
+namespace {
+
+struct Buf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct TextLayerW {
+    // forward (T = compute dtype)
+    void *qkv_w = nullptr, *so_w = nullptr, *cq_w = nullptr, *co_w = nullptr, *i_w = nullptr, *o_w = nullptr;
+    float *qkv_b = nullptr, *so_b = nullptr, *sln_w = nullptr, *sln_b = nullptr, *cq_b = nullptr, *co_b = nullptr,
+          *cln_w = nullptr, *cln_b = nullptr, *i_b = nullptr, *o_b = nullptr, *oln_w = nullptr, *oln_b = nullptr;
+    // backward (transposed copies, layers >= stash_layer)
+    void *o_wT = nullptr, *i_wT = nullptr, *co_wT = nullptr, *cq_wT = nullptr, *so_wT = nullptr, *qkv_wT = nullptr;
+};
+
+struct TextLayerA {
+    void* qkv = nullptr;       // T [R,3H]
+    float* Ps = nullptr;       // [B,nh,L,L]
+    float *a_hat = nullptr, *a_rstd = nullptr, *a_out = nullptr;
+    void* a_outT = nullptr;
+    void* qc = nullptr;        // T [R,H]
+    float* Pc = nullptr;       // [B,nh,L,Nst]  (layers >= stash only)
+    float *c_hat = nullptr, *c_rstd = nullptr, *c_out = nullptr;
+    void* c_outT = nullptr;
+    float* u = nullptr;        // [R,I]
+    float *o_hat = nullptr, *o_rstd = nullptr, *h_out = nullptr;
+    void* h_outT = nullptr;
+};
+
+struct VitLayerW {
+    float *n1w, *n1b, *n2w, *n2b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+
+}  // namespace
+
+struct pnp_engine {
+    pnp_config c{};
+    int bf = 0;
+    size_t esz = 4;
+    int P = 0, PP = 0, N = 0, Npad = 0, D = 0, H = 0, I = 0, TL = 0, nh = 0, Nst = 0, SL = 0;
+    char err[512] = {0};
+    std::vector<void*> allocs;
+    size_t alloc_bytes = 0;
+    std::map<std::string, Buf> named;          // raw fp32 device copies of small params + test buffers
+    std::map<std::string, bool> loaded;
+    bool finalized = false;
+
+    // ---- weights
+    float *cls = nullptr, *pos = nullptr, *patch_b = nullptr, *vnorm_w = nullptr, *vnorm_b = nullptr;
+    void* patch_w = nullptr;
+    std::vector<VitLayerW> vit;
+    float *word = nullptr, *tpos = nullptr, *eln_w = nullptr, *eln_b = nullptr, *itm_w = nullptr, *itm_b = nullptr;
+    std::vector<TextLayerW> txt;
+    void *ck_w = nullptr, *cv_w = nullptr;     // cross K / V weights of all layers: [TL*H, D]
+    float *ck_b = nullptr, *cv_b = nullptr;    // [TL*H]
+    std::vector<Buf> staging;                  // fp32 staging of GEMM weights until finalize
+
+    // ---- activations
+    void *patches = nullptr, *xn = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *h1 = nullptr, *embT = nullptr;
+    float *x = nullptr, *emb32 = nullptr;
+    void *Knat = nullptr, *Vnat = nullptr, *Kt = nullptr, *Vt = nullptr;
+    std::vector<TextLayerA> ta;
+    float *temb = nullptr, *h0 = nullptr, *tmp = nullptr;
+    void *h0T = nullptr, *ctx_s = nullptr, *ctx_c = nullptr, *g = nullptr;
+    // backward
+    float *dh = nullptr, *d_pre = nullptr, *dc = nullptr, *d_cpre = nullptr, *da = nullptr, *d_apre = nullptr,
+          *dctx_s = nullptr, *dS = nullptr, *dPc = nullptr;
+    void *d_preT = nullptr, *dg = nullptr, *d_cpreT = nullptr, *dctxc = nullptr, *dqc = nullptr, *d_apreT = nullptr,
+         *dqkv = nullptr;
+    // drop loop
+    float* G = nullptr;
+    uint8_t* dropped = nullptr;
+    float* logits_scratch = nullptr;
+
+    // ---- post-process state
+    struct Post {
+        bool reserved = false, prepared = false, has_crf = false;
+        int maxB = 0, maxK = 0, max_pix_img = 0, chunk = 0;
+        int64_t max_total_pix = 0;
+        int B = 0, Cmax = 0, Kmax = 0, maxHW = 0;
+        int64_t total_pix = 0;
+        std::vector<PostDesc> desc;
+        PostDesc* d_desc = nullptr;
+        int32_t *d_img_cls_off = nullptr, *d_cls_off = nullptr, *d_tok_idx = nullptr, *d_cls_div = nullptr, *d_lut = nullptr;
+        int lut_stride = 0;
+        size_t* d_label_off = nullptr;
+        double* d_wts = nullptr;
+        int32_t* d_wt_off = nullptr;
+        float *merged = nullptr, *thr = nullptr, *maps = nullptr, *maps2 = nullptr, *maps3 = nullptr, *stats = nullptr;
+        float *unary = nullptr, *Q = nullptr, *tmpq = nullptr, *va = nullptr, *vb = nullptr, *norm[2] = {nullptr, nullptr};
+        const uint8_t* d_rgb = nullptr;
+        const float* d_gt = nullptr;
+        CrfLattice lat[2]{};
+        uint64_t *keys_a = nullptr, *keys_b = nullptr;
+        uint32_t* vals_a = nullptr;
+        int *head = nullptr, *incl = nullptr, *seg_begin[2] = {nullptr, nullptr}, *seg_end[2] = {nullptr, nullptr}, *range_err = nullptr;
+        void* sort_tmp = nullptr;
+        size_t sort_tmp_bytes = 0;
+        size_t cap[2] = {0, 0};
+        size_t val_cap = 0;
+        int lut_cap = 0, cls_cap = 0, tok_cap = 0, wts_cap = 0;
+        bool maps_in_2 = false;   // where the current maps live after blur
+    } post;
+};
+
+namespace {
+
+int fail(pnp_engine* e, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e->err, sizeof(e->err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                      \
+    do {                                                                                     \
+        hipError_t _s = (call);                                                              \
+        if (_s != hipSuccess) return fail(e, PNP_ERR_HIP, "%s: %s", #call, hipGetErrorString(_s)); \
+    } while (0)
+#define KCHK(e, call)                                                         \
+    do {                                                                      \
+        int _r = (call);                                                      \
+        if (_r != PNP_OK) return fail(e, _r, "%s failed (%d): %s", #call, _r, hipGetErrorString(hipGetLastError())); \
+    } while (0)
+
+template <typename T>
+int dalloc(pnp_engine* e, T** out, size_t count, bool zero = false) {
+    void* p = nullptr;
+    const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
+    if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return fail(e, PNP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    if (zero && hipMemset(p, 0, bytes ? bytes : 256) != hipSuccess) return fail(e, PNP_ERR_HIP, "hipMemset failed");
+    e->allocs.push_back(p);
+    e->alloc_bytes += bytes;
+    *out = reinterpret_cast<T*>(p);
+    return PNP_OK;
+}
+int dalloc_t(pnp_engine* e, void** out, size_t count, bool zero = false) {   // `count` elements of the compute type
+    char* p = nullptr;
+    int r = dalloc<char>(e, &p, count * e->esz, zero);
+    *out = p;
+    return r;
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+    const size_t n = strlen(suf);
+    return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+__global__ void transpose_cast_kernel_f32(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = by + i, c = bx + threadIdx.x;
+        t[i][threadIdx.x] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int c = bx + i, r = by + threadIdx.x;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = t[threadIdx.x][i];
+    }
+}
+
+// fp32 [rows, cols] staging -> compute-type device weight (optionally transposed)
+int make_weight(pnp_engine* e, const float* src32, int rows, int cols, bool transpose, void** out) {
+    KCHK(e, dalloc_t(e, out, (size_t)rows * cols));
+    const float* s = src32;
+    float* tmp = nullptr;
+    if (transpose) {
+        HIPCHK(e, hipMalloc((void**)&tmp, (size_t)rows * cols * 4));
+        hipLaunchKernelGGL(transpose_cast_kernel_f32, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, 0, src32, tmp,
+                           rows, cols);
+        s = tmp;
+    }
+    int r = cast_f32(e->bf, s, *out, (size_t)rows * cols, 0);
+    hipError_t st = hipDeviceSynchronize();
+    if (tmp) (void)hipFree(tmp);
+    if (r != PNP_OK || st != hipSuccess) return fail(e, PNP_ERR_HIP, "weight conversion failed");
+    return PNP_OK;
+}
+
+GemmArgs G_(const void* A, int lda, const void* B, int ldb, int M, int N, int K) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.M = M; g.N = N; g.K = K;
+    return g;
+}
+
+const char* kVitNames[] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
+                           "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+                           "mlp.fc2.weight", "mlp.fc2.bias"};
+
+}  // namespace
+
+// =========================================================================================== lifetime
+
+extern "C" size_t pnp_workspace_bytes(const pnp_config* c) {
+    if (!c) return 0;
+    const size_t es = c->compute_bf16 ? 2 : 4;
+    const size_t P = c->img_size / c->patch, N = P * P + 1, Npad = (N + 63) / 64 * 64, D = c->vit_dim, H = c->txt_hidden,
+                 I = c->txt_inter, TL = c->txt_layers, B = c->max_batch, L = c->max_text_len;
+    const size_t M = B * N, R = B * L;
+    size_t w = (size_t)c->vit_depth * (12 * D * D) * es + TL * (4 * H * H + 2 * H * D + 2 * H * I) * es * 2 +
+               ((size_t)c->vocab + c->max_pos) * H * 4;
+    size_t a = M * (768 + D * 2 + 2 * D + D + 4 * D) * es + M * D * 8 + D * B * Npad * es + M * TL * H * es * 2 +
+               2 * TL * H * B * Npad * es;
+    size_t t = TL * (R * (3 * H + 2 * H) * es + R * (H * 8 + I) * 4 + B * (H / 64) * L * (L + Npad) * 4) + R * I * (4 + es) * 2 +
+               R * H * 64;
+    return w + a + t + (64u << 20);
+}
+
+extern "C" const char* pnp_last_error(const pnp_engine* e) { return e ? e->err : "null engine"; }
+
+extern "C" void pnp_destroy(pnp_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->c.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    for (auto& b : e->staging) if (b.p) (void)hipFree(b.p);
+    delete e;
+}
+
+extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
+    if (!cfg || !out) return PNP_ERR_ARG;
+    pnp_engine* e = new pnp_engine();
+    *out = e;
+    e->c = *cfg;
+    const pnp_config& c = e->c;
+    e->bf = c.compute_bf16 ? 1 : 0;
+    e->esz = e->bf ? 2 : 4;
+    if (c.patch != 16) return fail(e, PNP_ERR_ARG, "patch must be 16");
+    if (c.img_size % 16 || c.img_size <= 0) return fail(e, PNP_ERR_ARG, "img_size must be a positive multiple of 16");
+    if (c.vit_dim != c.vit_heads * 64 || c.txt_hidden != c.txt_heads * 64)
+        return fail(e, PNP_ERR_ARG, "head_dim must be 64 (vit_dim=%d heads=%d, txt_hidden=%d heads=%d)", c.vit_dim,
+                    c.vit_heads, c.txt_hidden, c.txt_heads);
+    if (c.vit_dim % 128 || c.txt_hidden % 128 || c.txt_inter % 128 || (c.vit_dim * c.vit_mlp_ratio) % 128)
+        return fail(e, PNP_ERR_ARG, "widths must be multiples of 128");
+    if (c.vit_dim > 1024 || c.txt_hidden > 1024) return fail(e, PNP_ERR_ARG, "LayerNorm width > 1024 unsupported");
+    if (c.max_text_len < 5 || c.max_text_len > 192) return fail(e, PNP_ERR_ARG, "max_text_len must be in [5,192]");
+    if (c.stash_layer < 0 || c.stash_layer >= c.txt_layers) return fail(e, PNP_ERR_ARG, "stash_layer out of range");
+    if (c.max_batch <= 0) return fail(e, PNP_ERR_ARG, "max_batch must be positive");
+    HIPCHK(e, hipSetDevice(c.device));
+    e->P = c.img_size / 16;
+    e->PP = e->P * e->P;
+    e->N = e->PP + 1;
+    e->Npad = (e->N + 63) / 64 * 64;
+    e->Nst = e->Npad;
+    e->D = c.vit_dim;
+    e->H = c.txt_hidden;
+    e->I = c.txt_inter;
+    e->TL = c.txt_layers;
+    e->nh = c.txt_heads;
+    e->SL = c.stash_layer;
+    if ((e->N + 15) / 16 > 160) return fail(e, PNP_ERR_ARG, "too many image tokens (%d) for the cross-attention kernel", e->N);
+    const size_t B = c.max_batch, M = B * e->N, D = e->D, H = e->H, I = e->I, L = c.max_text_len, R = B * L, TL = e->TL;
+    const size_t ldv = B * e->Npad;
+    e->vit.resize(c.vit_depth);
+    e->txt.resize(TL);
+    e->ta.resize(TL);
+    // activations
+    KCHK(e, dalloc_t(e, &e->patches, B * e->PP * 768));
+    KCHK(e, dalloc(e, &e->x, M * D));
+    KCHK(e, dalloc_t(e, &e->xn, M * D));
+    KCHK(e, dalloc_t(e, &e->qk, M * 2 * D));
+    KCHK(e, dalloc_t(e, &e->vt, D * ldv, true));
+    KCHK(e, dalloc_t(e, &e->ctx, M * D));
+    KCHK(e, dalloc_t(e, &e->h1, M * D * c.vit_mlp_ratio));
+    KCHK(e, dalloc_t(e, &e->embT, M * D));
+    KCHK(e, dalloc(e, &e->emb32, M * D));
+    const int nVn = e->TL - e->SL, nKt = e->TL - e->SL - 1;
+    KCHK(e, dalloc_t(e, &e->Knat, M * TL * H));
+    KCHK(e, dalloc_t(e, &e->Vnat, M * (size_t)nVn * H));
+    KCHK(e, dalloc_t(e, &e->Vt, TL * H * ldv, true));
+    if (nKt > 0) KCHK(e, dalloc_t(e, &e->Kt, (size_t)nKt * H * ldv, true));
+    KCHK(e, dalloc(e, &e->temb, R * H));
+    KCHK(e, dalloc(e, &e->h0, R * H));
+    KCHK(e, dalloc_t(e, &e->h0T, R * H));
+    KCHK(e, dalloc(e, &e->tmp, R * H));
+    KCHK(e, dalloc_t(e, &e->ctx_s, R * H));
+    KCHK(e, dalloc_t(e, &e->ctx_c, R * H));
+    KCHK(e, dalloc_t(e, &e->g, R * I));
+    for (size_t i = 0; i < TL; i++) {
+        TextLayerA& a = e->ta[i];
+        KCHK(e, dalloc_t(e, &a.qkv, R * 3 * H));
+        KCHK(e, dalloc(e, &a.a_hat, R * H));
+        KCHK(e, dalloc(e, &a.a_rstd, R));
+        KCHK(e, dalloc(e, &a.a_out, R * H));
+        KCHK(e, dalloc_t(e, &a.a_outT, R * H));
+        KCHK(e, dalloc_t(e, &a.qc, R * H));
+        KCHK(e, dalloc(e, &a.c_hat, R * H));
+        KCHK(e, dalloc(e, &a.c_rstd, R));
+        KCHK(e, dalloc(e, &a.c_out, R * H));
+        KCHK(e, dalloc_t(e, &a.c_outT, R * H));
+        KCHK(e, dalloc(e, &a.u, R * I));
+        KCHK(e, dalloc(e, &a.o_hat, R * H));
+        KCHK(e, dalloc(e, &a.o_rstd, R));
+        KCHK(e, dalloc(e, &a.h_out, R * H));
+        KCHK(e, dalloc_t(e, &a.h_outT, R * H));
+        if ((int)i >= e->SL) {
+            KCHK(e, dalloc(e, &a.Ps, B * e->nh * L * L));
+            KCHK(e, dalloc(e, &a.Pc, B * e->nh * L * (size_t)e->Nst, true));
+        }
+    }
+    KCHK(e, dalloc(e, &e->dh, R * H));
+    KCHK(e, dalloc(e, &e->d_pre, R * H));
+    KCHK(e, dalloc_t(e, &e->d_preT, R * H));
+    KCHK(e, dalloc_t(e, &e->dg, R * I));
+    KCHK(e, dalloc(e, &e->dc, R * H));
+    KCHK(e, dalloc(e, &e->d_cpre, R * H));
+    KCHK(e, dalloc_t(e, &e->d_cpreT, R * H));
+    KCHK(e, dalloc_t(e, &e->dctxc, R * H));
+    KCHK(e, dalloc_t(e, &e->dqc, R * H));
+    KCHK(e, dalloc(e, &e->da, R * H));
+    KCHK(e, dalloc(e, &e->d_apre, R * H));
+    KCHK(e, dalloc_t(e, &e->d_apreT, R * H));
+    KCHK(e, dalloc(e, &e->dctx_s, R * H));
+    KCHK(e, dalloc(e, &e->dS, B * e->nh * L * L));
+    KCHK(e, dalloc(e, &e->dPc, B * e->nh * L * (size_t)e->Nst, true));
+    KCHK(e, dalloc_t(e, &e->dqkv, R * 3 * H));
+    KCHK(e, dalloc(e, &e->G, B * L * (size_t)e->PP));
+    KCHK(e, dalloc(e, &e->dropped, B * (size_t)e->PP, true));
+    KCHK(e, dalloc(e, &e->logits_scratch, B * 2));
+    // small fp32 params
+    KCHK(e, dalloc(e, &e->cls, D));
+    KCHK(e, dalloc(e, &e->pos, (size_t)e->N * D));
+    KCHK(e, dalloc(e, &e->patch_b, D));
+    KCHK(e, dalloc(e, &e->vnorm_w, D));
+    KCHK(e, dalloc(e, &e->vnorm_b, D));
+    KCHK(e, dalloc(e, &e->word, (size_t)c.vocab * H));
+    KCHK(e, dalloc(e, &e->tpos, (size_t)c.max_pos * H));
+    KCHK(e, dalloc(e, &e->eln_w, H));
+    KCHK(e, dalloc(e, &e->eln_b, H));
+    KCHK(e, dalloc(e, &e->itm_w, 2 * H));
+    KCHK(e, dalloc(e, &e->itm_b, 2));
+    KCHK(e, dalloc(e, &e->ck_b, TL * H));
+    KCHK(e, dalloc(e, &e->cv_b, TL * H));
+    for (auto& v : e->vit) {
+        KCHK(e, dalloc(e, &v.n1w, D)); KCHK(e, dalloc(e, &v.n1b, D)); KCHK(e, dalloc(e, &v.n2w, D)); KCHK(e, dalloc(e, &v.n2b, D));
+        KCHK(e, dalloc(e, &v.qkv_b, 3 * D)); KCHK(e, dalloc(e, &v.proj_b, D));
+        KCHK(e, dalloc(e, &v.fc1_b, D * c.vit_mlp_ratio)); KCHK(e, dalloc(e, &v.fc2_b, D));
+        v.qkv_w = v.proj_w = v.fc1_w = v.fc2_w = nullptr;
+    }
+    for (auto& t : e->txt) {
+        KCHK(e, dalloc(e, &t.qkv_b, 3 * H)); KCHK(e, dalloc(e, &t.so_b, H)); KCHK(e, dalloc(e, &t.sln_w, H)); KCHK(e, dalloc(e, &t.sln_b, H));
+        KCHK(e, dalloc(e, &t.cq_b, H)); KCHK(e, dalloc(e, &t.co_b, H)); KCHK(e, dalloc(e, &t.cln_w, H)); KCHK(e, dalloc(e, &t.cln_b, H));
+        KCHK(e, dalloc(e, &t.i_b, I)); KCHK(e, dalloc(e, &t.o_b, H)); KCHK(e, dalloc(e, &t.oln_w, H)); KCHK(e, dalloc(e, &t.oln_b, H));
+    }
+    return PNP_OK;
+}
+
+// =========================================================================================== weights
+
+namespace {
+
+struct Slot {
+    float* small = nullptr;    // direct fp32 destination (biases, LN, embeddings)
+    size_t small_off = 0;      // element offset inside `small`
+    bool gemm = false;         // GEMM weight: staged fp32 until finalize
+    int rows = 0, cols = 0;
+};
+
+// resolve a reference state-dict key
+bool resolve(pnp_engine* e, const std::string& n, Slot& s) {
+    const int D = e->D, H = e->H, I = e->I;
+    auto small = [&](float* p, int count, size_t off = 0) { s.small = p; s.small_off = off; s.rows = 1; s.cols = count; return true; };
+    auto gemm = [&](int r, int c) { s.gemm = true; s.rows = r; s.cols = c; return true; };
+    if (n == "visual_encoder.cls_token") return small(e->cls, D);
+    if (n == "visual_encoder.pos_embed") return small(e->pos, e->N * D);
+    if (n == "visual_encoder.patch_embed.proj.weight") return gemm(D, 768);
+    if (n == "visual_encoder.patch_embed.proj.bias") return small(e->patch_b, D);
+    if (n == "visual_encoder.norm.weight") return small(e->vnorm_w, D);
+    if (n == "visual_encoder.norm.bias") return small(e->vnorm_b, D);
+    if (n == "text_encoder.embeddings.word_embeddings.weight") return small(e->word, e->c.vocab * H);
+    if (n == "text_encoder.embeddings.position_embeddings.weight") return small(e->tpos, e->c.max_pos * H);
+    if (n == "text_encoder.embeddings.LayerNorm.weight") return small(e->eln_w, H);
+    if (n == "text_encoder.embeddings.LayerNorm.bias") return small(e->eln_b, H);
+    if (n == "itm_head.weight") return small(e->itm_w, 2 * H);
+    if (n == "itm_head.bias") return small(e->itm_b, 2);
+    int li = -1;
+    char rest[128];
+    if (sscanf(n.c_str(), "visual_encoder.blocks.%d.%127s", &li, rest) == 2 && li >= 0 && li < e->c.vit_depth) {
+        VitLayerW& v = e->vit[li];
+        const std::string r(rest);
+        const int F = D * e->c.vit_mlp_ratio;
+        if (r == "norm1.weight") return small(v.n1w, D);
+        if (r == "norm1.bias") return small(v.n1b, D);
+        if (r == "norm2.weight") return small(v.n2w, D);
+        if (r == "norm2.bias") return small(v.n2b, D);
+        if (r == "attn.qkv.bias") return small(v.qkv_b, 3 * D);
+        if (r == "attn.proj.bias") return small(v.proj_b, D);
+        if (r == "mlp.fc1.bias") return small(v.fc1_b, F);
+        if (r == "mlp.fc2.bias") return small(v.fc2_b, D);
+        if (r == "attn.qkv.weight") return gemm(3 * D, D);
+        if (r == "attn.proj.weight") return gemm(D, D);
+        if (r == "mlp.fc1.weight") return gemm(F, D);
+        if (r == "mlp.fc2.weight") return gemm(D, F);
+        return false;
+    }
+    if (sscanf(n.c_str(), "text_encoder.encoder.layer.%d.%127s", &li, rest) == 2 && li >= 0 && li < e->TL) {
+        TextLayerW& t = e->txt[li];
+        const std::string r(rest);
+        if (r == "attention.self.query.bias") return small(t.qkv_b, H, 0);
+        if (r == "attention.self.key.bias") return small(t.qkv_b, H, H);
+        if (r == "attention.self.value.bias") return small(t.qkv_b, H, 2 * H);
+        if (r == "attention.output.dense.bias") return small(t.so_b, H);
+        if (r == "attention.output.LayerNorm.weight") return small(t.sln_w, H);
+        if (r == "attention.output.LayerNorm.bias") return small(t.sln_b, H);
+        if (r == "crossattention.self.query.bias") return small(t.cq_b, H);
+        if (r == "crossattention.self.key.bias") return small(e->ck_b, H, (size_t)li * H);
+        if (r == "crossattention.self.value.bias") return small(e->cv_b, H, (size_t)li * H);
+        if (r == "crossattention.output.dense.bias") return small(t.co_b, H);
+        if (r == "crossattention.output.LayerNorm.weight") return small(t.cln_w, H);
+        if (r == "crossattention.output.LayerNorm.bias") return small(t.cln_b, H);
+        if (r == "intermediate.dense.bias") return small(t.i_b, I);
+        if (r == "output.dense.bias") return small(t.o_b, H);
+        if (r == "output.LayerNorm.weight") return small(t.oln_w, H);
+        if (r == "output.LayerNorm.bias") return small(t.oln_b, H);
+        if (r == "attention.self.query.weight" || r == "attention.self.key.weight" || r == "attention.self.value.weight" ||
+            r == "attention.output.dense.weight" || r == "crossattention.self.query.weight" ||
+            r == "crossattention.output.dense.weight")
+            return gemm(H, H);
+        if (r == "crossattention.self.key.weight" || r == "crossattention.self.value.weight") return gemm(H, D);
+        if (r == "intermediate.dense.weight") return gemm(I, H);
+        if (r == "output.dense.weight") return gemm(H, I);
+        return false;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" int pnp_load_weight(pnp_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim,
+                               int32_t on_device) {
+    if (!e || !name || !data || !shape) return PNP_ERR_ARG;
+    if (e->finalized) return fail(e, PNP_ERR_STATE, "weights already finalized");
+    HIPCHK(e, hipSetDevice(e->c.device));
+    Slot s;
+    if (!resolve(e, name, s)) return PNP_OK;          // strict=False: not a tensor of this path
+    size_t count = 1;
+    for (int i = 0; i < ndim; i++) count *= (size_t)shape[i];
+    if (count != (size_t)s.rows * s.cols) return fail(e, PNP_ERR_ARG, "%s: expected %d elements, got %zu", name, s.rows * s.cols, count);
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (s.small) {
+        HIPCHK(e, hipMemcpy(s.small + s.small_off, data, count * 4, kind));
+    } else {
+        Buf b;
+        b.bytes = count * 4;
+        HIPCHK(e, hipMalloc(&b.p, b.bytes));
+        HIPCHK(e, hipMemcpy(b.p, data, b.bytes, kind));
+        e->staging.push_back(b);
+        e->named[std::string("stage:") + name] = b;
+    }
+    e->loaded[name] = true;
+    return PNP_OK;
+}
+
+extern "C" int pnp_finalize_weights(pnp_engine* e) {
+    if (!e) return PNP_ERR_ARG;
+    if (e->finalized) return PNP_OK;
+    HIPCHK(e, hipSetDevice(e->c.device));
+    const int D = e->D, H = e->H, I = e->I, TL = e->TL;
+    auto stage = [&](const std::string& n) -> const float* {
+        auto it = e->named.find("stage:" + n);
+        return it == e->named.end() ? nullptr : (const float*)it->second.p;
+    };
+#define NEED(ptr, nm)                                                         \
+    const float* ptr = stage(nm);                                             \
+    if (!ptr) return fail(e, PNP_ERR_STATE, "missing weight %s", std::string(nm).c_str());
+    // every small tensor must have arrived too
+    {
+        const char* smalls[] = {"visual_encoder.cls_token", "visual_encoder.pos_embed", "visual_encoder.patch_embed.proj.bias",
+                                "visual_encoder.norm.weight", "visual_encoder.norm.bias",
+                                "text_encoder.embeddings.word_embeddings.weight", "text_encoder.embeddings.position_embeddings.weight",
+                                "text_encoder.embeddings.LayerNorm.weight", "text_encoder.embeddings.LayerNorm.bias",
+                                "itm_head.weight", "itm_head.bias"};
+        for (const char* s : smalls)
+            if (!e->loaded.count(s)) return fail(e, PNP_ERR_STATE, "missing weight %s", s);
+    }
+    {
+        NEED(pw, "visual_encoder.patch_embed.proj.weight");
+        KCHK(e, make_weight(e, pw, D, 768, false, &e->patch_w));
+    }
+    const int F = D * e->c.vit_mlp_ratio;
+    for (int i = 0; i < e->c.vit_depth; i++) {
+        const std::string b = "visual_encoder.blocks." + std::to_string(i) + ".";
+        for (const char* k : kVitNames)
+            if (!e->loaded.count(b + k)) return fail(e, PNP_ERR_STATE, "missing weight %s%s", b.c_str(), k);
+        NEED(w0, b + "attn.qkv.weight");
+        NEED(w1, b + "attn.proj.weight");
+        NEED(w2, b + "mlp.fc1.weight");
+        NEED(w3, b + "mlp.fc2.weight");
+        KCHK(e, make_weight(e, w0, 3 * D, D, false, &e->vit[i].qkv_w));
+        KCHK(e, make_weight(e, w1, D, D, false, &e->vit[i].proj_w));
+        KCHK(e, make_weight(e, w2, F, D, false, &e->vit[i].fc1_w));
+        KCHK(e, make_weight(e, w3, D, F, false, &e->vit[i].fc2_w));
+    }
+    // cross-attention K / V weights of all layers, layer-major, so one GEMM projects every layer
+    KCHK(e, dalloc_t(e, &e->ck_w, (size_t)TL * H * D));
+    KCHK(e, dalloc_t(e, &e->cv_w, (size_t)TL * H * D));
+    for (int i = 0; i < TL; i++) {
+        const std::string b = "text_encoder.encoder.layer." + std::to_string(i) + ".";
+        TextLayerW& t = e->txt[i];
+        const char* req[] = {"attention.self.query.bias", "attention.self.key.bias", "attention.self.value.bias",
+                             "attention.output.dense.bias", "attention.output.LayerNorm.weight", "attention.output.LayerNorm.bias",
+                             "crossattention.self.query.bias", "crossattention.self.key.bias", "crossattention.self.value.bias",
+                             "crossattention.output.dense.bias", "crossattention.output.LayerNorm.weight",
+                             "crossattention.output.LayerNorm.bias", "intermediate.dense.bias", "output.dense.bias",
+                             "output.LayerNorm.weight", "output.LayerNorm.bias"};
+        for (const char* k : req)
+            if (!e->loaded.count(b + k)) return fail(e, PNP_ERR_STATE, "missing weight %s%s", b.c_str(), k);
+        NEED(wq, b + "attention.self.query.weight");
+        NEED(wk, b + "attention.self.key.weight");
+        NEED(wv, b + "attention.self.value.weight");
+        NEED(wso, b + "attention.output.dense.weight");
+        NEED(wcq, b + "crossattention.self.query.weight");
+        NEED(wck, b + "crossattention.self.key.weight");
+        NEED(wcv, b + "crossattention.self.value.weight");
+        NEED(wco, b + "crossattention.output.dense.weight");
+        NEED(wi, b + "intermediate.dense.weight");
+        NEED(wo, b + "output.dense.weight");
+        // fused self q|k|v [3H, H]
+        float* fused = nullptr;
+        HIPCHK(e, hipMalloc((void**)&fused, (size_t)3 * H * H * 4));
+        HIPCHK(e, hipMemcpy(fused, wq, (size_t)H * H * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(e, hipMemcpy(fused + (size_t)H * H, wk, (size_t)H * H * 4, hipMemcpyDeviceToDevice));
+        HIPCHK(e, hipMemcpy(fused + (size_t)2 * H * H, wv, (size_t)H * H * 4, hipMemcpyDeviceToDevice));
+        int r = make_weight(e, fused, 3 * H, H, false, &t.qkv_w);
+        if (r == PNP_OK && i > e->SL) r = make_weight(e, fused, 3 * H, H, true, &t.qkv_wT);
+        (void)hipFree(fused);
+        if (r != PNP_OK) return r;
+        KCHK(e, make_weight(e, wso, H, H, false, &t.so_w));
+        KCHK(e, make_weight(e, wcq, H, H, false, &t.cq_w));
+        KCHK(e, make_weight(e, wco, H, H, false, &t.co_w));
+        KCHK(e, make_weight(e, wi, I, H, false, &t.i_w));
+        KCHK(e, make_weight(e, wo, H, I, false, &t.o_w));
+        KCHK(e, cast_f32(e->bf, wck, (char*)e->ck_w + (size_t)i * H * D * e->esz, (size_t)H * D, 0));
+        KCHK(e, cast_f32(e->bf, wcv, (char*)e->cv_w + (size_t)i * H * D * e->esz, (size_t)H * D, 0));
+        if (i >= e->SL) {
+            KCHK(e, make_weight(e, wo, H, I, true, &t.o_wT));      // [I][H]
+            KCHK(e, make_weight(e, wi, I, H, true, &t.i_wT));      // [H][I]
+            KCHK(e, make_weight(e, wco, H, H, true, &t.co_wT));
+        }
+        if (i > e->SL) {
+            KCHK(e, make_weight(e, wcq, H, H, true, &t.cq_wT));
+            KCHK(e, make_weight(e, wso, H, H, true, &t.so_wT));
+        }
+    }
+#undef NEED
+    HIPCHK(e, hipDeviceSynchronize());
+    for (auto& b : e->staging) if (b.p) (void)hipFree(b.p);
+    e->staging.clear();
+    for (auto it = e->named.begin(); it != e->named.end();) {
+        if (it->first.rfind("stage:", 0) == 0) it = e->named.erase(it);
+        else ++it;
+    }
+    e->finalized = true;
+    return PNP_OK;
+}
+
+// =========================================================================================== model
+
+extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream) {
+    if (!e || !d_images) return PNP_ERR_ARG;
+    if (!e->finalized) return fail(e, PNP_ERR_STATE, "weights not finalized");
+    if (B <= 0 || B > e->c.max_batch) return fail(e, PNP_ERR_ARG, "batch %d out of range (max %d)", B, e->c.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = e->D, N = e->N, M = B * N, F = D * e->c.vit_mlp_ratio, bf = e->bf;
+    const int ldv = e->c.max_batch * e->Npad;
+    KCHK(e, patchify(bf, d_images, d_dropped, e->patches, B, e->c.img_size, e->P, s));
+    KCHK(e, cls_rows(e->cls, e->pos, e->x, B, N, D, s));
+    {
+        GemmArgs g = G_(e->patches, 768, e->patch_w, 768, B * e->PP, D, 768);
+        g.bias = e->patch_b; g.resid = e->pos; g.ldr = D; g.out_f32 = e->x; g.ldo = D; g.row_div = e->PP;
+        KCHK(e, gemm_nt(bf, g, s));
+    }
+    const float scale = 1.0f / sqrtf(64.f);
+    for (int l = 0; l < e->c.vit_depth; l++) {
+        const VitLayerW& w = e->vit[l];
+        KCHK(e, layernorm(bf, e->x, w.n1w, w.n1b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s));
+        {   // q | k  natural: [M, 2D]
+            GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 2 * D, D);
+            g.bias = w.qkv_b; g.out_t = e->qk; g.ldo_t = 2 * D;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        {   // V^T: [D, B*Npad] = Wv . xn^T, token columns padded per image
+            GemmArgs g = G_((const char*)w.qkv_w + (size_t)2 * D * D * e->esz, D, e->xn, D, D, M, D);
+            g.bias = w.qkv_b + 2 * D; g.bias_on_rows = 1; g.out_t = e->vt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, vit_attention(bf, e->qk, 2 * D, D, e->vt, ldv, e->Npad, e->ctx, B, e->c.vit_heads, N, scale, s));
+        {
+            GemmArgs g = G_(e->ctx, D, w.proj_w, D, M, D, D);
+            g.bias = w.proj_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, layernorm(bf, e->x, w.n2w, w.n2b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s));
+        {
+            GemmArgs g = G_(e->xn, D, w.fc1_w, D, M, F, D);
+            g.bias = w.fc1_b; g.mode = GEMM_EPI_GELU; g.out_t = e->h1; g.ldo_t = F;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        {
+            GemmArgs g = G_(e->h1, F, w.fc2_w, F, M, D, F);
+            g.bias = w.fc2_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+    }
+    KCHK(e, layernorm(bf, e->x, e->vnorm_w, e->vnorm_b, e->c.vit_ln_eps, M, D, e->emb32, e->embT, nullptr, nullptr, s));
+    // cross-attention K / V projections of all text layers in four GEMMs (natural + transposed layouts)
+    const int H = e->H, TL = e->TL, SL = e->SL;
+    {
+        GemmArgs g = G_(e->embT, D, e->ck_w, D, M, TL * H, D);
+        g.bias = e->ck_b; g.out_t = e->Knat; g.ldo_t = TL * H;
+        KCHK(e, gemm_nt(bf, g, s));
+    }
+    {
+        GemmArgs g = G_(e->cv_w, D, e->embT, D, TL * H, M, D);
+        g.bias = e->cv_b; g.bias_on_rows = 1; g.out_t = e->Vt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
+        KCHK(e, gemm_nt(bf, g, s));
+    }
+    {
+        const int nVn = TL - SL;
+        GemmArgs g = G_(e->embT, D, (const char*)e->cv_w + (size_t)SL * H * D * e->esz, D, M, nVn * H, D);
+        g.bias = e->cv_b + (size_t)SL * H; g.out_t = e->Vnat; g.ldo_t = nVn * H;
+        KCHK(e, gemm_nt(bf, g, s));
+    }
+    if (TL - SL - 1 > 0) {
+        const int nKt = TL - SL - 1;
+        GemmArgs g = G_((const char*)e->ck_w + (size_t)(SL + 1) * H * D * e->esz, D, e->embT, D, nKt * H, M, D);
+        g.bias = e->ck_b + (size_t)(SL + 1) * H; g.bias_on_rows = 1; g.out_t = e->Kt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
+        KCHK(e, gemm_nt(bf, g, s));
+    }
+    return PNP_OK;
+}
+
+extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const int64_t* d_mask, int32_t ld, int32_t B,
+                                      int32_t L, float* d_logits, void* stream) {
+    if (!e || !d_ids || !d_mask) return PNP_ERR_ARG;
+    if (!e->finalized) return fail(e, PNP_ERR_STATE, "weights not finalized");
+    if (B <= 0 || B > e->c.max_batch || L < 5 || L > e->c.max_text_len || ld < L)
+        return fail(e, PNP_ERR_ARG, "text batch %d x %d (ld %d) out of range (max %d x %d)", B, L, ld, e->c.max_batch, e->c.max_text_len);
+    hipStream_t s = (hipStream_t)stream;
+    const int H = e->H, I = e->I, TL = e->TL, R = B * L, bf = e->bf, N = e->N, D = e->D;
+    const int ldv = e->c.max_batch * e->Npad;
+    (void)D;
+    KCHK(e, text_embed(d_ids, ld, e->word, e->tpos, e->temb, B, L, H, e->c.enc_token_id, e->c.vocab, s));
+    KCHK(e, layernorm(bf, e->temb, e->eln_w, e->eln_b, e->c.txt_ln_eps, R, H, e->h0, e->h0T, nullptr, nullptr, s));
+    const float* h = e->h0;
+    const void* hT = e->h0T;
+    for (int i = 0; i < TL; i++) {
+        const TextLayerW& w = e->txt[i];
+        TextLayerA& a = e->ta[i];
+        const bool stash = i >= e->SL;
+        {
+            GemmArgs g = G_(hT, H, w.qkv_w, H, R, 3 * H, H);
+            g.bias = w.qkv_b; g.out_t = a.qkv; g.ldo_t = 3 * H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, text_self_attn(bf, a.qkv, d_mask, ld, e->ctx_s, stash ? a.Ps : nullptr, B, L, H, s));
+        {
+            GemmArgs g = G_(e->ctx_s, H, w.so_w, H, R, H, H);
+            g.bias = w.so_b; g.resid = h; g.ldr = H; g.out_f32 = e->tmp; g.ldo = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, layernorm(bf, e->tmp, w.sln_w, w.sln_b, e->c.txt_ln_eps, R, H, a.a_out, a.a_outT, a.a_hat, a.a_rstd, s));
+        {
+            GemmArgs g = G_(a.a_outT, H, w.cq_w, H, R, H, H);
+            g.bias = w.cq_b; g.out_t = a.qc; g.ldo_t = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, xattn(bf, 0, (const char*)e->Knat + (size_t)i * H * e->esz, TL * H,
+                      (const char*)e->Vt + (size_t)i * H * ldv * e->esz, ldv, e->Npad, a.qc, H, e->ctx_c, H,
+                      stash ? a.Pc : nullptr, e->Nst, B, L, N, e->nh, s));
+        {
+            GemmArgs g = G_(e->ctx_c, H, w.co_w, H, R, H, H);
+            g.bias = w.co_b; g.resid = a.a_out; g.ldr = H; g.out_f32 = e->tmp; g.ldo = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, layernorm(bf, e->tmp, w.cln_w, w.cln_b, e->c.txt_ln_eps, R, H, a.c_out, a.c_outT, a.c_hat, a.c_rstd, s));
+        {
+            GemmArgs g = G_(a.c_outT, H, w.i_w, H, R, I, H);
+            g.bias = w.i_b; g.mode = GEMM_EPI_GELU; g.aux = a.u; g.ld_aux = I; g.out_t = e->g; g.ldo_t = I;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        {
+            GemmArgs g = G_(e->g, I, w.o_w, I, R, H, I);
+            g.bias = w.o_b; g.resid = a.c_out; g.ldr = H; g.out_f32 = e->tmp; g.ldo = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, layernorm(bf, e->tmp, w.oln_w, w.oln_b, e->c.txt_ln_eps, R, H, a.h_out, a.h_outT, a.o_hat, a.o_rstd, s));
+        h = a.h_out;
+        hT = a.h_outT;
+    }
+    KCHK(e, itm_head(h, e->itm_w, e->itm_b, d_logits ? d_logits : e->logits_scratch, B, L, H, s));
+    return PNP_OK;
+}
+
+extern "C" int pnp_xattn_grad(pnp_engine* e, int32_t B, int32_t L, void* stream) {
+    if (!e) return PNP_ERR_ARG;
+    if (!e->finalized) return fail(e, PNP_ERR_STATE, "weights not finalized");
+    if (B <= 0 || B > e->c.max_batch || L < 5 || L > e->c.max_text_len) return fail(e, PNP_ERR_ARG, "bad B/L");
+    hipStream_t s = (hipStream_t)stream;
+    const int H = e->H, I = e->I, TL = e->TL, R = B * L, bf = e->bf, N = e->N, SL = e->SL;
+    const int ldv = e->c.max_batch * e->Npad, nVn = TL - SL;
+    KCHK(e, itm_grad_seed(e->itm_w, e->dh, B, L, H, s));
+    for (int i = TL - 1; i >= SL; i--) {
+        const TextLayerW& w = e->txt[i];
+        TextLayerA& a = e->ta[i];
+        KCHK(e, layernorm_bwd(bf, e->dh, w.oln_w, a.o_hat, a.o_rstd, R, H, e->d_pre, e->d_preT, s));
+        {   // dg = (d_pre . Wo2) * gelu'(u)
+            GemmArgs g = G_(e->d_preT, H, w.o_wT, H, R, I, H);
+            g.mode = GEMM_EPI_GELU_GRAD; g.aux = a.u; g.ld_aux = I; g.out_t = e->dg; g.ldo_t = I;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        {   // dc = d_pre + dg . Wi
+            GemmArgs g = G_(e->dg, I, w.i_wT, I, R, H, I);
+            g.resid = e->d_pre; g.ldr = H; g.out_f32 = e->dc; g.ldo = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, layernorm_bwd(bf, e->dc, w.cln_w, a.c_hat, a.c_rstd, R, H, e->d_cpre, e->d_cpreT, s));
+        {
+            GemmArgs g = G_(e->d_cpreT, H, w.co_wT, H, R, H, H);
+            g.out_t = e->dctxc; g.ldo_t = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        const char* vnat = (const char*)e->Vnat + (size_t)(i - SL) * H * e->esz;
+        if (i == SL) {
+            KCHK(e, xattn(bf, 2, vnat, nVn * H, nullptr, 0, e->Npad, e->dctxc, H, nullptr, 0, e->dPc, e->Nst, B, L, N, e->nh, s));
+            break;
+        }
+        KCHK(e, xattn(bf, 1, vnat, nVn * H, (const char*)e->Kt + (size_t)(i - SL - 1) * H * ldv * e->esz, ldv, e->Npad,
+                      e->dctxc, H, e->dqc, H, a.Pc, e->Nst, B, L, N, e->nh, s));
+        {
+            GemmArgs g = G_(e->dqc, H, w.cq_wT, H, R, H, H);
+            g.resid = e->d_cpre; g.ldr = H; g.out_f32 = e->da; g.ldo = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, layernorm_bwd(bf, e->da, w.sln_w, a.a_hat, a.a_rstd, R, H, e->d_apre, e->d_apreT, s));
+        {
+            GemmArgs g = G_(e->d_apreT, H, w.so_wT, H, R, H, H);
+            g.out_f32 = e->dctx_s; g.ldo = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+        KCHK(e, text_self_attn_bwd(bf, a.qkv, e->dctx_s, a.Ps, e->dS, e->dqkv, B, L, H, s));
+        {
+            GemmArgs g = G_(e->dqkv, 3 * H, w.qkv_wT, 3 * H, R, H, 3 * H);
+            g.resid = e->d_apre; g.ldr = H; g.out_f32 = e->dh; g.ldo = H;
+            KCHK(e, gemm_nt(bf, g, s));
+        }
+    }
+    return PNP_OK;
+}
+
+extern "C" int pnp_gradcam_gather(pnp_engine* e, const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t head,
+                                  float* d_out, void* stream) {
+    if (!e || !d_mask || !d_out) return PNP_ERR_ARG;
+    if (head < 0 || head >= e->nh) return fail(e, PNP_ERR_ARG, "head %d out of range", head);
+    if (B <= 0 || B > e->c.max_batch || L < 5 || L > e->c.max_text_len || ld < L) return fail(e, PNP_ERR_ARG, "bad B/L/ld");
+    KCHK(e, gradcam_gather(e->ta[e->SL].Pc, e->dPc, d_mask, ld, d_out, B, e->nh, head, L, e->Nst, e->PP, (hipStream_t)stream));
+    return PNP_OK;
+}
+
+extern "C" int pnp_compute_gradcam(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
+                                   const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t head, float* d_out,
+                                   float* d_logits, void* stream) {
+    int r = pnp_vit_forward(e, d_images, d_dropped, B, stream);
+    if (r) return r;
+    r = pnp_text_forward_xattn(e, d_ids, d_mask, ld, B, L, d_logits, stream);
+    if (r) return r;
+    r = pnp_xattn_grad(e, B, L, stream);
+    if (r) return r;
+    return pnp_gradcam_gather(e, d_mask, ld, B, L, head, d_out, stream);
+}
+
+extern "C" int pnp_drop_step(pnp_engine* e, const float* d_gradcam, float* d_g0, float* d_agg, uint8_t* d_dropped,
+                             int32_t* d_picks, int32_t iter, int32_t B, int32_t T, int32_t npick, int32_t max_picks,
+                             void* stream) {
+    if (!e || !d_gradcam || !d_agg || !d_dropped || (npick > 0 && !d_picks)) return PNP_ERR_ARG;
+    if (T < 4) return fail(e, PNP_ERR_ARG, "T=%d too short", T);
+    KCHK(e, drop_step(d_gradcam, d_g0, d_agg, d_dropped, d_picks, iter, B, T, e->PP, npick, max_picks, (hipStream_t)stream));
+    return PNP_OK;
+}
+
+extern "C" int pnp_drop_loop(pnp_engine* e, const float* d_images, const int64_t* d_ids, const int64_t* d_mask, int32_t ld,
+                             int32_t B, int32_t L, int32_t head, int32_t drop_iter, int32_t npick, float* d_g0,
+                             float* d_agg, int32_t* d_picks, float* d_logits, void* stream) {
+    if (!e || !d_images || !d_ids || !d_mask || !d_g0) return PNP_ERR_ARG;
+    if (drop_iter < 1) return fail(e, PNP_ERR_ARG, "drop_iter must be >= 1");
+    if (drop_iter == 1)   // PnP.py:565-575: single call, no aggregate
+        return pnp_compute_gradcam(e, d_images, nullptr, d_ids, d_mask, ld, B, L, head, d_g0, d_logits, stream);
+    if (!d_agg || !d_picks) return PNP_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(e, hipMemsetAsync(e->dropped, 0, (size_t)B * e->PP, s));
+    for (int it = 0; it < drop_iter; it++) {
+        int r = pnp_compute_gradcam(e, d_images, e->dropped, d_ids, d_mask, ld, B, L, head, e->G, d_logits, stream);
+        if (r) return r;
+        r = pnp_drop_step(e, e->G, d_g0, d_agg, e->dropped, d_picks, it, B, L - 1, npick, drop_iter * npick, stream);
+        if (r) return r;
+    }
+    return PNP_OK;
+}
+
+// =========================================================================================== post-process
+
+extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_total_pixels, int32_t max_pixels_per_image,
+                                int32_t max_channels, int32_t crf_chunk) {
+    if (!e) return PNP_ERR_ARG;
+    if (e->post.reserved) return fail(e, PNP_ERR_STATE, "post-process workspace already reserved");
+    if (max_batch <= 0 || max_total_pixels <= 0 || max_pixels_per_image <= 0 || max_channels <= 0 || max_channels > 255)
+        return fail(e, PNP_ERR_ARG, "bad post-process bounds");
+    HIPCHK(e, hipSetDevice(e->c.device));
+    auto& p = e->post;
+    p.maxB = max_batch;
+    p.max_total_pix = max_total_pixels;
+    p.max_pix_img = max_pixels_per_image;
+    p.maxK = max_channels;
+    p.chunk = crf_chunk > 0 ? crf_chunk : max_batch;
+    const size_t TP = (size_t)max_total_pixels, K = max_channels, B = max_batch;
+    KCHK(e, dalloc(e, &p.d_desc, B));
+    KCHK(e, dalloc(e, &p.d_img_cls_off, B + 1));
+    p.cls_cap = (int)(B * K + 1);
+    p.tok_cap = (int)(B * e->c.max_text_len + 1);
+    KCHK(e, dalloc(e, &p.d_cls_off, p.cls_cap + 1));
+    KCHK(e, dalloc(e, &p.d_cls_div, p.cls_cap));
+    KCHK(e, dalloc(e, &p.d_tok_idx, p.tok_cap));
+    p.lut_cap = (int)(B * (K + 1));
+    KCHK(e, dalloc(e, &p.d_lut, p.lut_cap));
+    KCHK(e, dalloc(e, &p.d_label_off, B + 1));
+    p.wts_cap = (int)(B * 4096);
+    KCHK(e, dalloc(e, &p.d_wts, p.wts_cap));
+    KCHK(e, dalloc(e, &p.d_wt_off, B + 1));
+    KCHK(e, dalloc(e, &p.merged, B * K * e->PP));
+    KCHK(e, dalloc(e, &p.thr, B * K * e->PP));
+    KCHK(e, dalloc(e, &p.maps, TP * K));
+    KCHK(e, dalloc(e, &p.maps2, TP * K));
+    KCHK(e, dalloc(e, &p.maps3, TP * K));
+    KCHK(e, dalloc(e, &p.stats, B * K * 2));
+    // CRF
+    KCHK(e, dalloc(e, &p.unary, TP * K));
+    KCHK(e, dalloc(e, &p.Q, TP * K));
+    KCHK(e, dalloc(e, &p.tmpq, TP * K));
+    KCHK(e, dalloc(e, &p.norm[0], TP));
+    KCHK(e, dalloc(e, &p.norm[1], TP));
+    for (int t = 0; t < 2; t++) {
+        const int D1 = t == 0 ? 3 : 6;
+        const size_t cap = TP * D1;
+        p.cap[t] = cap;
+        CrfLattice& L = p.lat[t];
+        L.D1 = D1;
+        L.which = t;
+        L.cap = cap;
+        KCHK(e, dalloc(e, &L.bary, cap));
+        KCHK(e, dalloc(e, &L.vals, cap));
+        KCHK(e, dalloc(e, &L.offset, cap));
+        KCHK(e, dalloc(e, &L.seg_start, cap + 1));
+        KCHK(e, dalloc(e, &L.ukeys, cap));
+        KCHK(e, dalloc(e, &L.idbase, B + 1));
+        KCHK(e, dalloc(e, &L.n1, cap * D1));
+        KCHK(e, dalloc(e, &L.n2, cap * D1));
+        KCHK(e, dalloc(e, &p.seg_begin[t], B));
+        KCHK(e, dalloc(e, &p.seg_end[t], B));
+    }
+    const size_t cap6 = p.cap[1];
+    KCHK(e, dalloc(e, &p.keys_a, cap6));
+    KCHK(e, dalloc(e, &p.keys_b, cap6));
+    KCHK(e, dalloc(e, &p.vals_a, cap6));
+    KCHK(e, dalloc(e, &p.head, cap6));
+    KCHK(e, dalloc(e, &p.incl, cap6));
+    KCHK(e, dalloc(e, &p.range_err, 1, true));
+    p.sort_tmp_bytes = crf_sort_temp_bytes(cap6, max_batch);
+    char* st = nullptr;
+    KCHK(e, dalloc(e, &st, p.sort_tmp_bytes));
+    p.sort_tmp = st;
+    // lattice value buffers: the images of one chunk, bilateral upper bound (6 entries per pixel) x K
+    const size_t chunk_pix = (size_t)std::min<int64_t>((int64_t)p.chunk * max_pixels_per_image, max_total_pixels);
+    p.val_cap = std::max(chunk_pix * 6 * K, cap6);
+    KCHK(e, dalloc(e, &p.va, p.val_cap));
+    KCHK(e, dalloc(e, &p.vb, p.val_cap));
+    p.reserved = true;
+    return PNP_OK;
+}
+
+extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t want_crf, void* stream) {
+    if (!e || !b) return PNP_ERR_ARG;
+    auto& p = e->post;
+    if (!p.reserved) return fail(e, PNP_ERR_STATE, "call pnp_post_reserve first");
+    if (b->B <= 0 || b->B > p.maxB) return fail(e, PNP_ERR_ARG, "post batch %d out of range", b->B);
+    if (!b->H || !b->W || !b->n_classes || !b->has_bg || !b->img_cls_off || !b->cls_off || !b->tok_idx || !b->cls_div || !b->lut)
+        return fail(e, PNP_ERR_ARG, "post batch has null tables");
+    if (want_crf && !b->d_rgb) return fail(e, PNP_ERR_ARG, "CRF needs d_rgb");
+    hipStream_t s = (hipStream_t)stream;
+    const int B = b->B;
+    p.prepared = false;
+    p.desc.assign(B, PostDesc{});
+    std::vector<size_t> label_off(B + 1, 0);
+    std::vector<int32_t> wt_off(B + 1, 0);
+    std::vector<double> wts;
+    size_t off = 0;
+    int64_t pix = 0;
+    p.Cmax = p.Kmax = p.maxHW = 0;
+    for (int i = 0; i < B; i++) {
+        PostDesc& d = p.desc[i];
+        d.H = b->H[i]; d.W = b->W[i]; d.C = b->n_classes[i]; d.has_bg = b->has_bg[i] ? 1 : 0; d.K = d.C + d.has_bg;
+        if (d.H <= 0 || d.W <= 0 || d.C <= 0 || d.K > p.maxK) return fail(e, PNP_ERR_ARG, "image %d: bad H/W/classes (K=%d max %d)", i, d.K, p.maxK);
+        if ((int64_t)d.H * d.W > p.max_pix_img) return fail(e, PNP_ERR_ARG, "image %d: %dx%d exceeds max_pixels_per_image", i, d.H, d.W);
+        if (b->img_cls_off[i + 1] - b->img_cls_off[i] != d.C) return fail(e, PNP_ERR_ARG, "image %d: merge plan has %d classes, expected %d", i, b->img_cls_off[i + 1] - b->img_cls_off[i], d.C);
+        d.pix0 = (int)pix;
+        d.off = off;
+        label_off[i] = (size_t)pix;
+        off += (size_t)d.K * d.H * d.W;
+        pix += (int64_t)d.H * d.W;
+        p.Cmax = std::max(p.Cmax, d.C);
+        p.Kmax = std::max(p.Kmax, d.K);
+        p.maxHW = std::max(p.maxHW, d.H * d.W);
+        // scipy _gaussian_kernel1d(sigma = 0.05 * max(H, W)), truncate 4.0  (PnP.py:1150, scale=0.05)
+        const double sigma = 0.05 * (double)std::max(d.H, d.W);
+        const int radius = (int)(4.0 * sigma + 0.5);
+        std::vector<double> phi(2 * radius + 1);
+        double sum = 0;
+        for (int x = -radius; x <= radius; x++) {
+            phi[x + radius] = std::exp(-0.5 / (sigma * sigma) * (double)(x * x));
+            sum += phi[x + radius];
+        }
+        wt_off[i] = (int32_t)wts.size();
+        if (b->blur_wts && b->blur_wt_off) {
+            for (int j = b->blur_wt_off[i]; j < b->blur_wt_off[i + 1]; j++) wts.push_back(b->blur_wts[j]);
+        } else {
+            for (int j = 0; j <= radius; j++) wts.push_back(phi[radius - j] / sum);   // weight at distance j (w[-j] == w[j])
+        }
+    }
+    wt_off[B] = (int32_t)wts.size();
+    label_off[B] = (size_t)pix;
+    if (pix > p.max_total_pix) return fail(e, PNP_ERR_ARG, "batch has %lld pixels, reserved %lld", (long long)pix, (long long)p.max_total_pix);
+    if ((int)wts.size() > p.wts_cap) return fail(e, PNP_ERR_ARG, "blur taps exceed reserved capacity");
+    const int ncls = b->img_cls_off[B], ntok = b->cls_off[ncls];
+    if (ncls > p.cls_cap || ntok > p.tok_cap) return fail(e, PNP_ERR_ARG, "merge plan exceeds reserved capacity");
+    if (b->lut_stride < p.Kmax || B * b->lut_stride > p.lut_cap) return fail(e, PNP_ERR_ARG, "bad lut_stride");
+    // lattice value offsets per chunk (upper bound: entries * K)
+    for (int c0 = 0; c0 < B; c0 += p.chunk) {
+        size_t v[2] = {0, 0};
+        for (int i = c0; i < std::min(B, c0 + p.chunk); i++)
+            for (int t = 0; t < 2; t++) {
+                p.desc[i].voff[t] = v[t];
+                v[t] += (size_t)p.desc[i].H * p.desc[i].W * (t == 0 ? 3 : 6) * p.desc[i].K;
+            }
+        if (v[1] > p.val_cap) return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", v[1], p.val_cap);
+    }
+    p.B = B;
+    p.total_pix = pix;
+    p.lut_stride = b->lut_stride;
+    p.d_rgb = b->d_rgb;
+    p.d_gt = b->d_gt;
+    HIPCHK(e, hipMemcpyAsync(p.d_desc, p.desc.data(), sizeof(PostDesc) * B, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_img_cls_off, b->img_cls_off, 4 * (B + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_cls_off, b->cls_off, 4 * (ncls + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_cls_div, b->cls_div, 4 * std::max(ncls, 1), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_tok_idx, b->tok_idx, 4 * std::max(ntok, 1), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_lut, b->lut, 4 * (size_t)B * b->lut_stride, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_label_off, label_off.data(), sizeof(size_t) * (B + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_wts, wts.data(), 8 * wts.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(p.d_wt_off, wt_off.data(), 4 * (B + 1), hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));      // host vectors above go out of scope
+    p.has_crf = false;
+    if (want_crf) {
+        // PnP.py:1036-1041: POS_XY_STD = 3, Bi_XY_STD = 50, Bi_RGB_STD = 5 (features are fixed per batch)
+        for (int t = 0; t < 2; t++) {
+            const int D1 = t == 0 ? 3 : 6;
+            std::vector<int> sb(B), se(B);
+            for (int i = 0; i < B; i++) {
+                sb[i] = p.desc[i].pix0 * D1;
+                se[i] = sb[i] + p.desc[i].H * p.desc[i].W * D1;
+            }
+            HIPCHK(e, hipMemcpyAsync(p.seg_begin[t], sb.data(), 4 * B, hipMemcpyHostToDevice, s));
+            HIPCHK(e, hipMemcpyAsync(p.seg_end[t], se.data(), 4 * B, hipMemcpyHostToDevice, s));
+            HIPCHK(e, hipStreamSynchronize(s));
+            KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
+                                      p.maxHW, p.seg_begin[t], p.seg_end[t], p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
+                                      p.sort_tmp, p.sort_tmp_bytes, p.range_err, s));
+            KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.va, p.vb, p.norm[t], s));
+        }
+        int err = 0;
+        HIPCHK(e, hipMemcpyAsync(&err, p.range_err, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(e, hipStreamSynchronize(s));
+        if (err) return fail(e, PNP_ERR_ARG, "lattice key out of packing range (image too large for the 64-bit key)");
+        p.has_crf = true;
+    }
+    p.prepared = true;
+    return PNP_OK;
+}
+
+#define POST_READY(e)                                                                     \
+    if (!(e)) return PNP_ERR_ARG;                                                         \
+    if (!(e)->post.prepared) return fail(e, PNP_ERR_STATE, "call pnp_post_prepare first");
+
+extern "C" int pnp_merge_tokens(pnp_engine* e, const float* d_gradcam, int32_t T, void* stream) {
+    POST_READY(e);
+    auto& p = e->post;
+    if (!d_gradcam || T < 5) return fail(e, PNP_ERR_ARG, "bad gradcam / T");
+    KCHK(e, merge_tokens(d_gradcam, p.d_cls_off, p.d_tok_idx, p.d_cls_div, p.d_img_cls_off, p.merged, p.B, T, e->PP, p.Cmax,
+                         (hipStream_t)stream));
+    return PNP_OK;
+}
+
+extern "C" int pnp_threshold_upsample(pnp_engine* e, float threshold, int32_t scale01, void* stream) {
+    POST_READY(e);
+    auto& p = e->post;
+    hipStream_t s = (hipStream_t)stream;
+    KCHK(e, threshold_maps(p.merged, p.d_img_cls_off, p.thr, threshold, p.B, e->PP, p.Cmax, s));
+    KCHK(e, upsample_maps(p.thr, p.d_desc, p.maps, p.B, e->P, p.Cmax, p.maxHW, s));
+    if (scale01) KCHK(e, minmax_normalize(p.maps, p.d_desc, p.stats, p.B, p.Cmax, p.maxHW, 1, s));
+    KCHK(e, background_channel(p.maps, p.d_desc, p.B, p.maxHW, s));
+    p.maps_in_2 = false;
+    return PNP_OK;
+}
+
+extern "C" int pnp_blur_minmax(pnp_engine* e, void* stream) {
+    POST_READY(e);
+    auto& p = e->post;
+    hipStream_t s = (hipStream_t)stream;
+    KCHK(e, blur_maps(p.maps, p.maps3, p.maps2, p.d_desc, p.d_wts, p.d_wt_off, p.B, p.Kmax, p.maxHW, s));
+    KCHK(e, minmax_normalize(p.maps2, p.d_desc, p.stats, p.B, p.Kmax, p.maxHW, 0, s));
+    p.maps_in_2 = true;
+    return PNP_OK;
+}
+
+extern "C" int pnp_densecrf(pnp_engine* e, int32_t iters, float pos_w, float pos_xy, float bi_w, float bi_xy, float bi_rgb,
+                            void* stream) {
+    POST_READY(e);
+    auto& p = e->post;
+    if (!p.has_crf) return fail(e, PNP_ERR_STATE, "batch was prepared without CRF lattices");
+    if (pos_xy != 3.0f || bi_xy != 50.0f || bi_rgb != 5.0f)
+        return fail(e, PNP_ERR_ARG, "lattices are built for sxy=3 / sxy=50, srgb=5 (PnP.py:1036-1041)");
+    hipStream_t s = (hipStream_t)stream;
+    const float* maps = p.maps_in_2 ? p.maps2 : p.maps;
+    KCHK(e, unary_from_maps(maps, p.d_desc, p.unary, p.B, p.maxHW, s));
+    for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
+        const int n = std::min(p.chunk, p.B - c0);
+        KCHK(e, crf_softmax(p.d_desc, c0, n, p.unary, p.Q, 1, p.maxHW, s));
+        for (int it = 0; it < iters; it++) {
+            KCHK(e, crf_pairwise(p.lat[0], p.d_desc, c0, n, p.Q, p.norm[0], p.unary, p.tmpq, p.va, p.vb, pos_w, 1, s));
+            KCHK(e, crf_pairwise(p.lat[1], p.d_desc, c0, n, p.Q, p.norm[1], p.unary, p.tmpq, p.va, p.vb, bi_w, 0, s));
+            KCHK(e, crf_softmax(p.d_desc, c0, n, p.tmpq, p.Q, 0, p.maxHW, s));
+        }
+    }
+    return PNP_OK;
+}
+
+extern "C" int pnp_remap_hist(pnp_engine* e, int32_t from_crf, uint8_t* d_labels, unsigned long long* d_hist, int32_t n_class,
+                              void* stream) {
+    POST_READY(e);
+    auto& p = e->post;
+    if (!d_labels) return fail(e, PNP_ERR_ARG, "d_labels is null");
+    hipStream_t s = (hipStream_t)stream;
+    const float* src = from_crf ? p.Q : (p.maps_in_2 ? p.maps2 : p.maps);
+    KCHK(e, argmax_remap(src, p.d_desc, p.d_lut, p.lut_stride, d_labels, p.d_label_off, from_crf ? 1 : 0, p.B, p.maxHW, s));
+    if (d_hist && p.d_gt) KCHK(e, confusion_hist(d_labels, p.d_gt, p.d_desc, p.d_label_off, d_hist, n_class, p.B, p.maxHW, s));
+    return PNP_OK;
+}
+
+extern "C" int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T, float threshold, int32_t scale01, int32_t mode,
+                               uint8_t* d_labels, unsigned long long* d_hist, int32_t n_class, void* stream) {
+    int r = pnp_merge_tokens(e, d_gradcam, T, stream);
+    if (r) return r;
+    r = pnp_threshold_upsample(e, threshold, scale01, stream);
+    if (r) return r;
+    if (mode & 1) {
+        r = pnp_blur_minmax(e, stream);
+        if (r) return r;
+    }
+    if (mode & 2) {
+        r = pnp_densecrf(e, 10, 7.0f, 3.0f, 10.0f, 50.0f, 5.0f, stream);
+        if (r) return r;
+    }
+    return pnp_remap_hist(e, (mode & 2) ? 1 : 0, d_labels, d_hist, n_class, stream);
+}
+
+// =========================================================================================== introspection
+
+extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, size_t* bytes) {
+    if (!e || !name || !d_ptr || !bytes) return PNP_ERR_ARG;
+    const std::string n(name);
+    const size_t B = e->c.max_batch, L = e->c.max_text_len;
+    auto& p = e->post;
+    auto set = [&](void* ptr, size_t b) { *d_ptr = ptr; *bytes = b; return PNP_OK; };
+    if (n == "image_embeds") return set(e->emb32, B * e->N * (size_t)e->D * 4);
+    if (n == "x") return set(e->x, B * e->N * (size_t)e->D * 4);
+    if (n == "P") return set(e->ta[e->SL].Pc, B * e->nh * L * (size_t)e->Nst * 4);
+    if (n == "dP") return set(e->dPc, B * e->nh * L * (size_t)e->Nst * 4);
+    if (n == "h_last") return set(e->ta[e->TL - 1].h_out, B * L * (size_t)e->H * 4);
+    if (n == "dropped") return set(e->dropped, B * (size_t)e->PP);
+    if (p.reserved) {
+        const size_t mk = (size_t)p.max_total_pix * p.maxK * 4;
+        if (n == "merged") return set(p.merged, (size_t)p.maxB * p.maxK * e->PP * 4);
+        if (n == "maps") return set(p.maps_in_2 ? p.maps2 : p.maps, mk);
+        if (n == "maps_pre_blur") return set(p.maps, mk);
+        if (n == "unary") return set(p.unary, mk);
+        if (n == "crf_q") return set(p.Q, mk);
+        if (n == "crf_idbase_gauss") return set(p.lat[0].idbase, ((size_t)p.maxB + 1) * 4);
+        if (n == "crf_idbase_bilateral") return set(p.lat[1].idbase, ((size_t)p.maxB + 1) * 4);
+        if (n == "crf_norm_gauss") return set(p.norm[0], (size_t)p.max_total_pix * 4);
+        if (n == "crf_norm_bilateral") return set(p.norm[1], (size_t)p.max_total_pix * 4);
+    }
+    return fail(e, PNP_ERR_ARG, "unknown buffer %s", name);
+}
+
+extern "C" int pnp_op_gemm(int32_t bf, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,
+                           int32_t K, const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo,
+                           int32_t gelu, void* stream) {
+    GemmArgs g = G_(d_A, lda, d_B, ldb, M, N, K);
+    g.bias = d_bias; g.resid = d_resid; g.ldr = ldr; g.out_f32 = d_out_f32; g.ldo = ldo;
+    g.mode = gelu ? GEMM_EPI_GELU : GEMM_EPI_LINEAR;
+    return gemm_nt(bf, g, (hipStream_t)stream);
+}
+
+extern "C" int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
+                                float* d_y, void* stream) {
+    return layernorm(0, d_x, d_w, d_b, eps, rows, D, d_y, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream) {
+    return cast_f32(to_bf16, d_in, d_out, (size_t)n, (hipStream_t)stream);
+}

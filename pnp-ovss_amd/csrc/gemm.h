@@ -1,0 +1,31 @@
+// Host-visible description of one fused NT GEMM launch (see gemm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pnp {
+
+enum { GEMM_EPI_LINEAR = 0, GEMM_EPI_GELU = 1, GEMM_EPI_GELU_GRAD = 2 };
+
+struct GemmArgs {
+    const void* A = nullptr;   // [M, lda] T
+    const void* B = nullptr;   // [N, ldb] T
+    int M = 0, N = 0, K = 0, lda = 0, ldb = 0;
+    int Nvalid = 0;            // set by gemm_nt (N before tile rounding)
+    int mode = GEMM_EPI_LINEAR;
+    const float* bias = nullptr;   // [N] (or [M] when bias_on_rows)
+    int bias_on_rows = 0;
+    const float* resid = nullptr;  // f32 [M, ldr] added after activation (or pos_embed when row_div>0)
+    int ldr = 0;
+    float* out_f32 = nullptr;      // optional f32 output [*, ldo]
+    int ldo = 0;
+    void* out_t = nullptr;         // optional T output [*, ldo_t]
+    int ldo_t = 0;
+    float* aux = nullptr;          // GELU: pre-activation stash (f32) ; GELU_GRAD: pre-activation input
+    int ld_aux = 0;
+    int row_div = 0;               // >0: patch rows -> token rows b*(row_div+1)+1+p, resid = pos_embed
+    int col_div = 0, col_pad = 0;  // >0: output column n -> (n / col_div) * col_pad + n % col_div
+};
+
+int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s);
+
+}  // namespace pnp

@@ -1,0 +1,93 @@
+// Host launchers of the hand-written gfx950 kernels (one .hip per group).  All return PNP_OK or a
+// negative errno-style code; none allocates or synchronises (graph-capture safe).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "gemm.h"
+
+namespace pnp {
+
+// Per-image descriptor of the post-process batch (images may have different original sizes and
+// class counts).  `off` = offset (in floats) of this image's K*H*W block inside the flat map /
+// unary / Q / tmp buffers; `pix0` = global index of its first pixel; `voff[t]` = offset of its
+// lattice value block (t = 0 Gaussian, 1 bilateral).
+struct PostDesc {
+    int H, W, K, C, has_bg, pix0;
+    size_t off;
+    size_t voff[2];
+};
+
+// One permutohedral lattice type for a whole image batch (device pointers).
+struct CrfLattice {
+    int D1;            // d + 1
+    int which;         // 0 Gaussian, 1 bilateral
+    size_t cap;        // capacity (entries) = stride of the neighbour tables
+    float* bary;       // [entries] barycentric weight per (pixel, vertex)
+    uint32_t* vals;    // [entries] sorted (pixel, vertex) indices = contributor lists
+    int* offset;       // [entries] lattice id per (pixel, vertex)
+    int* seg_start;    // [M+1] first sorted entry of each lattice point
+    uint64_t* ukeys;   // [M] sorted unique packed keys
+    int* idbase;       // [B+1] first lattice id of each image
+    int* n1;           // [(d+1) * cap]
+    int* n2;
+};
+
+// vit_kernels.hip
+int patchify(int bf, const float* img, const uint8_t* dropped, void* out, int B, int S, int P, hipStream_t s);
+int cls_rows(const float* cls, const float* pos, float* x, int B, int N, int D, hipStream_t s);
+int layernorm(int bf, const float* x, const float* w, const float* b, float eps, int rows, int D, float* y, void* yt,
+              float* xhat, float* rstd, hipStream_t s);
+int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
+                  int H, int N, float scale, hipStream_t s);
+
+// text_kernels.hip
+int text_embed(const int64_t* ids, int ld_ids, const float* word, const float* pos, float* out, int B, int L, int H,
+               int enc_id, int vocab, hipStream_t s);
+int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, void* ctx, float* probs, int B, int L,
+                   int H, hipStream_t s);
+int text_self_attn_bwd(int bf, const void* qkv, const float* dctx, const float* probs, float* ds_scratch, void* dqkv,
+                       int B, int L, int H, hipStream_t s);
+int xattn(int bf, int mode, const void* a1, int ld1, const void* a2t, int ld2, int Npad, const void* x, int ldx,
+          void* out, int ldo, float* pbuf, int Nst, int B, int L, int N, int nheads, hipStream_t s);
+int layernorm_bwd(int bf, const float* dy, const float* w, const float* xhat, const float* rstd, int rows, int D,
+                  float* dx, void* dxt, hipStream_t s);
+int itm_head(const float* hlast, const float* w, const float* bias, float* logits, int B, int L, int H, hipStream_t s);
+int itm_grad_seed(const float* w, float* dh, int B, int L, int H, hipStream_t s);
+int cast_f32(int bf, const float* in, void* out, size_t n, hipStream_t s);
+
+// pipeline_kernels.hip
+int gradcam_gather(const float* P, const float* dP, const int64_t* mask, int ld_mask, float* out, int B, int nheads,
+                   int head, int L, int Nst, int PP, hipStream_t s);
+int drop_step(const float* G, float* g0, float* agg, uint8_t* dropped, int32_t* picks, int iter, int B, int T, int PP,
+              int npick, int max_picks, hipStream_t s);
+int merge_tokens(const float* src, const int32_t* cls_off, const int32_t* tok_idx, const int32_t* cls_div,
+                 const int32_t* img_cls_off, float* out, int B, int T, int PP, int Cmax, hipStream_t s);
+int threshold_maps(const float* merged, const int32_t* img_cls_off, float* out, float threshold, int B, int PP, int Cmax,
+                   hipStream_t s);
+int upsample_maps(const float* src, const PostDesc* desc, float* maps, int B, int P, int Cmax, int maxHW, hipStream_t s);
+int minmax_normalize(float* maps, const PostDesc* desc, float* stats, int B, int Kmax, int maxHW, int class_channels_only,
+                     hipStream_t s);
+int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipStream_t s);
+int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
+              int B, int Kmax, int maxHW, hipStream_t s);
+int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, hipStream_t s);
+int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int lut_stride, uint8_t* labels,
+                 const size_t* label_off, int pixel_major, int B, int maxHW, hipStream_t s);
+int confusion_hist(const uint8_t* labels, const float* gt, const PostDesc* desc, const size_t* label_off,
+                   unsigned long long* hist, int n_class, int B, int maxHW, hipStream_t s);
+
+// crf.hip
+size_t crf_sort_temp_bytes(size_t max_entries, int max_images);
+int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
+                      int B, size_t ent_total, int max_pixels, const int* d_seg_begin, const int* d_seg_end,
+                      uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, void* temp,
+                      size_t temp_bytes, int* d_range_err, hipStream_t s);
+int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, float* va, float* vb, float* norm_out,
+                     hipStream_t s);
+int crf_pairwise(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
+                 const float* unary, float* tmp, float* va, float* vb, float w, int first, hipStream_t s);
+int crf_softmax(const PostDesc* d_imgs, int img0, int nimg, const float* x, float* Q, int neg, int max_pixels,
+                hipStream_t s);
+
+}  // namespace pnp

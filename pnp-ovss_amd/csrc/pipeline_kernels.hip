@@ -1,0 +1,454 @@
+// GradCAM gather, the device-resident salience-drop bookkeeping, word-piece merge, and the
+// HBM-bound post-process kernels (threshold + bilinear upsample, Scale_0_1, background,
+// separable Gaussian blur + min-max, softmax/unary, argmax + remap + confusion histogram).
+// Reference (PnP.py = PnP_OVSS_0514_updated_segmentation.py):
+//   gather      blip_image_text_matching.py:411-435
+//   drop loop   PnP.py:587-647, 716-721
+//   merge       PnP.py:810-853
+//   threshold / upsample / Scale_0_1 / background   PnP.py:348-379, 424-455, 1078-1094
+//   blur        PnP.py:1149-1153 (scipy.ndimage.gaussian_filter: reflect, truncate 4, double acc)
+//   remap/hist  PnP.py:390-399, 1106-1146
+#include "common.h"
+#include "kernels.h"
+#include "../../include/pnp_math.h"
+
+namespace pnp {
+
+// ------------------------------------------------------------------------------------------
+// G[b, t, p] = max(P[b,h,t+1,1+p] * relu(dP[b,h,t+1,1+p]) * mask[b,t+1], 0)
+__global__ void gradcam_gather_kernel(const float* __restrict__ P, const float* __restrict__ dP,
+                                      const int64_t* __restrict__ mask, int ld_mask, float* __restrict__ out, int B,
+                                      int nheads, int head, int L, int Nst, int PP) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = L - 1;
+    if (idx >= B * T * PP) return;
+    const int p = idx % PP, t = (idx / PP) % T, b = idx / (PP * T);
+    const size_t o = (((size_t)b * nheads + head) * L + (t + 1)) * Nst + 1 + p;
+    const float g = P[o] * fmaxf(dP[o], 0.f) * (float)mask[(size_t)b * ld_mask + t + 1];
+    out[idx] = g < 0.f ? 0.f : g;
+}
+
+// ------------------------------------------------------------------------------------------
+// One salience-drop iteration for one image (one workgroup per image), fully on device:
+//   pred = G with already-picked cells zeroed  -> g0 (iter 0) and agg (l0 + l0 + l1 + ...)
+//   salience = sum_{t=3}^{T-2} G[t]  (un-zeroed copy), picked cells -> 0, take the `npick` largest
+//   (ties: larger index wins, i.e. a stable ascending argsort's tail), append to picks and flag
+//   them in `dropped` for the next forward's patch gather.
+__device__ __forceinline__ uint64_t sal_key(float v, int idx) {
+    uint32_t u = __float_as_uint(v);
+    u = (v != v) ? 0xffffffffu : ((u & 0x80000000u) ? ~u : (u | 0x80000000u));   // order-preserving, NaN largest
+    return ((uint64_t)u << 32) | (uint32_t)idx;
+}
+
+__global__ __launch_bounds__(256) void drop_step_kernel(const float* __restrict__ G, float* __restrict__ g0,
+                                                        float* __restrict__ agg, uint8_t* __restrict__ dropped,
+                                                        int32_t* __restrict__ picks, int iter, int T, int PP,
+                                                        int npick, int max_picks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sal = reinterpret_cast<float*>(smem);                 // [PP]
+    __shared__ uint64_t red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* Gb = G + (size_t)b * T * PP;
+    uint8_t* dr = dropped + (size_t)b * PP;
+    for (int p = tid; p < PP; p += 256) {
+        float s = 0.f;
+        for (int t = 3; t < T - 1; t++) s += Gb[(size_t)t * PP + p];
+        sal[p] = dr[p] ? 0.f : s;
+    }
+    for (int i = tid; i < T * PP; i += 256) {
+        const int p = i % PP;
+        const float v = dr[p] ? 0.f : Gb[i];
+        const size_t o = (size_t)b * T * PP + i;
+        if (iter == 0) {
+            if (g0) g0[o] = v;
+            agg[o] = v + v;
+        } else {
+            agg[o] += v;
+        }
+    }
+    __syncthreads();
+    if (npick <= 0) return;
+    // npick rounds of block-wide arg-max on (value, index) keys; results are emitted in ascending
+    // order like np.argsort(...)[-npick:] (order is irrelevant downstream, kept for parity dumps)
+    for (int k = 0; k < npick; k++) {
+        uint64_t best = 0;
+        for (int p = tid; p < PP; p += 256) {
+            const uint64_t key = sal_key(sal[p], p);
+            const bool taken = (__float_as_uint(sal[p]) == 0xffc00001u);
+            if (!taken && key > best) best = key;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint64_t other = __shfl_xor(best, o, 64);
+            best = other > best ? other : best;
+        }
+        if ((tid & 63) == 0) red[tid >> 6] = best;
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t m = red[0];
+            for (int w = 1; w < 4; w++) m = red[w] > m ? red[w] : m;
+            const int p = (int)(m & 0xffffffffu);
+            const int slot = iter * npick + (npick - 1 - k);
+            if (slot < max_picks) picks[(size_t)b * max_picks + slot] = p;
+            sal[p] = __uint_as_float(0xffc00001u);               // tombstone (a NaN payload we never produce)
+        }
+        __syncthreads();
+    }
+    for (int k = tid; k < npick; k += 256) {
+        const int slot = iter * npick + k;
+        if (slot < max_picks) dr[picks[(size_t)b * max_picks + slot]] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Word-piece -> class merge, table driven (host builds the plan once per caption):
+// merged[b, c] = (sum_{k in tokens(c), in order} src[b, 3 + tok_k]) / div(c)   (div applied only if != 1)
+__global__ void merge_tokens_kernel(const float* __restrict__ src, const int32_t* __restrict__ cls_off,
+                                    const int32_t* __restrict__ tok_idx, const int32_t* __restrict__ cls_div,
+                                    const int32_t* __restrict__ img_cls_off, float* __restrict__ out, int T, int PP,
+                                    int Cmax) {
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int c0 = img_cls_off[b], nc = img_cls_off[b + 1] - c0;
+    if (c >= nc) return;
+    const int k0 = cls_off[c0 + c], k1 = cls_off[c0 + c + 1];
+    const int div = cls_div[c0 + c];
+    const float* sb = src + (size_t)b * T * PP;
+    for (int p = threadIdx.x; p < PP; p += blockDim.x) {
+        float acc = 0.f;
+        if (k1 > k0) {
+            acc = sb[(size_t)(3 + tok_idx[k0]) * PP + p];
+            for (int k = k0 + 1; k < k1; k++) acc += sb[(size_t)(3 + tok_idx[k]) * PP + p];
+            if (div != 1) acc = acc / (float)div;
+        }
+        out[((size_t)b * Cmax + c) * PP + p] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per (image, class): (m - min) / (max - min) >= threshold -> m * mask   (NaN -> mask false)
+__global__ __launch_bounds__(256) void threshold_kernel(const float* __restrict__ merged, const int32_t* __restrict__ img_cls_off,
+                                                        float* __restrict__ out, float threshold, int PP, int Cmax) {
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int nc = img_cls_off[b + 1] - img_cls_off[b];
+    if (c >= nc) return;
+    __shared__ float smn[4], smx[4];
+    const float* m = merged + ((size_t)b * Cmax + c) * PP;
+    float mn = INFINITY, mx = -INFINITY;
+    int nan = 0;
+    for (int p = tid; p < PP; p += 256) {
+        const float v = m[p];
+        nan |= (v != v);
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    if ((tid & 63) == 0) { smn[tid >> 6] = mn; smx[tid >> 6] = mx; }
+    nan = __syncthreads_or(nan);
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    const float den = nan ? __uint_as_float(0x7fc00000u) : mx - mn;   // torch min()/max() propagate NaN
+    for (int p = tid; p < PP; p += 256) {
+        const float v = m[p];
+        const float nrm = (v - mn) / den;
+        out[((size_t)b * Cmax + c) * PP + p] = (nrm >= threshold) ? v : v * 0.0f;   // v*False keeps NaN/inf semantics
+    }
+}
+
+// Bilinear align_corners=True upsample, torch generic-kernel arithmetic:
+// out = fma(top, w0h, bot*w1h), top = fma(v00, w0w, v01*w1w), bot = fma(v10, w0w, v11*w1w).
+__device__ __forceinline__ void src_index(int dst, int in_size, float scale, int& i0, int& i1, float& w0, float& w1) {
+    const float real = __fmul_rn(scale, (float)dst);
+    int f = (int)floorf(real);
+    f = f < in_size - 1 ? f : in_size - 1;
+    float lam = __fsub_rn(real, (float)f);
+    lam = fminf(fmaxf(lam, 0.f), 1.f);
+    i0 = f;
+    i1 = f + (f < in_size - 1 ? 1 : 0);
+    w1 = lam;
+    w0 = __fsub_rn(1.f, lam);
+}
+
+__global__ void upsample_kernel(const float* __restrict__ src, const PostDesc* __restrict__ desc, float* __restrict__ maps,
+                                int P, int Cmax) {
+    const int b = blockIdx.z, c = blockIdx.y;
+    const PostDesc d = desc[b];
+    if (c >= d.C) return;
+    const int H = d.H, W = d.W;
+    const float sh = H > 1 ? __fdiv_rn((float)(P - 1), (float)(H - 1)) : 0.f;
+    const float sw = W > 1 ? __fdiv_rn((float)(P - 1), (float)(W - 1)) : 0.f;
+    const float* s = src + ((size_t)b * Cmax + c) * P * P;
+    float* o = maps + d.off + (size_t)(c + d.has_bg) * H * W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < H * W; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        int h0, h1, w0i, w1i;
+        float a, bb, cc, dd;
+        src_index(y, P, sh, h0, h1, a, bb);
+        src_index(x, P, sw, w0i, w1i, cc, dd);
+        const float v00 = s[h0 * P + w0i], v01 = s[h0 * P + w1i], v10 = s[h1 * P + w0i], v11 = s[h1 * P + w1i];
+        const float top = fmaf(v00, cc, __fmul_rn(v01, dd));
+        const float bot = fmaf(v10, cc, __fmul_rn(v11, dd));
+        o[i] = fmaf(top, a, __fmul_rn(bot, bb));
+    }
+}
+
+// per (image, channel) min / max over H*W -> stats[(b*Kmax + k)*2 + {0,1}]
+__global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc,
+                                                     float* __restrict__ stats, int Kmax, int first_k_is_class) {
+    const int b = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
+    const PostDesc d = desc[b];
+    const int kk = first_k_is_class ? k + d.has_bg : k;       // Scale_0_1 touches class channels only
+    if (kk >= d.K) return;
+    if (first_k_is_class && d.C == 1) return;                 // Scale_0_1 on a squeezed 2-D map is a no-op (PnP.py:1079-1080)
+    __shared__ float smn[4], smx[4];
+    const float* m = maps + d.off + (size_t)kk * d.H * d.W;
+    float mn = INFINITY, mx = -INFINITY;
+    bool nan = false;
+    const int n = d.H * d.W;
+    for (int p = tid; p < n; p += 256) {
+        const float v = m[p];
+        nan |= (v != v);
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        nan |= (bool)__shfl_xor((int)nan, o, 64);
+    }
+    __shared__ int snan[4];
+    if ((tid & 63) == 0) { smn[tid >> 6] = mn; smx[tid >> 6] = mx; snan[tid >> 6] = nan; }
+    __syncthreads();
+    if (tid == 0) {
+        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        if (snan[0] | snan[1] | snan[2] | snan[3]) mn = mx = __uint_as_float(0x7fc00000u);   // numpy/torch min/max propagate NaN
+        stats[((size_t)b * Kmax + kk) * 2 + 0] = mn;
+        stats[((size_t)b * Kmax + kk) * 2 + 1] = mx;
+    }
+}
+
+// x = (x - min) / (max - min)   [x -= min ; x /= x.max()  in fp32, PnP.py:1151-1152 / :1086-1087]
+__global__ void normalize_kernel(float* __restrict__ maps, const PostDesc* __restrict__ desc, const float* __restrict__ stats,
+                                 int Kmax, int first_k_is_class) {
+    const int b = blockIdx.z, k = blockIdx.y;
+    const PostDesc d = desc[b];
+    const int kk = first_k_is_class ? k + d.has_bg : k;
+    if (kk >= d.K) return;
+    if (first_k_is_class && d.C == 1) return;
+    const float mn = stats[((size_t)b * Kmax + kk) * 2], mx = stats[((size_t)b * Kmax + kk) * 2 + 1];
+    const float den = __fsub_rn(mx, mn);
+    float* m = maps + d.off + (size_t)kk * d.H * d.W;
+    const int n = d.H * d.W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        m[i] = __fdiv_rn(__fsub_rn(m[i], mn), den);
+}
+
+// background channel 0 = (max over class channels == 0)
+__global__ void background_kernel(float* __restrict__ maps, const PostDesc* __restrict__ desc) {
+    const int b = blockIdx.y;
+    const PostDesc d = desc[b];
+    if (!d.has_bg) return;
+    const int n = d.H * d.W;
+    float* m = maps + d.off;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float mx = m[(size_t)n + i];
+        bool nan = mx != mx;
+        for (int c = 1; c < d.C; c++) {
+            const float v = m[(size_t)(1 + c) * n + i];
+            nan |= (v != v);
+            mx = fmaxf(mx, v);
+        }
+        m[i] = (!nan && mx == 0.f) ? 1.f : 0.f;          // torch.max propagates NaN; NaN == 0 is False
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// scipy.ndimage.correlate1d (symmetric kernel, mode='reflect') along one axis, double
+// accumulation in scipy's order: tmp = x[i]*w[0]; for j = r..1: tmp += (x[i-j] + x[i+j]) * w[j].
+// wts[j] = weight at distance j (j = 0..radius), float64.  fp32 in / fp32 out.
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    // half-sample symmetric: (d c b a | a b c d | d c b a), valid for any offset
+    const int period = 2 * n;
+    int m = i % period;
+    if (m < 0) m += period;
+    return m >= n ? period - 1 - m : m;
+}
+
+__global__ void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out, const PostDesc* __restrict__ desc,
+                                 const double* __restrict__ wts, const int32_t* __restrict__ wt_off, int axis) {
+    const int b = blockIdx.z, k = blockIdx.y;
+    const PostDesc d = desc[b];
+    if (k >= d.K) return;
+    const int H = d.H, W = d.W, n = H * W;
+    const double* w = wts + wt_off[b];
+    const int radius = wt_off[b + 1] - wt_off[b] - 1;
+    const float* src = in + d.off + (size_t)k * n;
+    float* dst = out + d.off + (size_t)k * n;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        double tmp;
+        if (axis == 0) {
+            tmp = __dmul_rn((double)src[i], w[0]);
+            for (int j = radius; j >= 1; j--) {
+                const double a = (double)src[reflect_idx(y - j, H) * W + x];
+                const double c = (double)src[reflect_idx(y + j, H) * W + x];
+                tmp = __dadd_rn(tmp, __dmul_rn(__dadd_rn(a, c), w[j]));
+            }
+        } else {
+            tmp = __dmul_rn((double)src[i], w[0]);
+            const float* row = src + (size_t)y * W;
+            for (int j = radius; j >= 1; j--) {
+                const double a = (double)row[reflect_idx(x - j, W)];
+                const double c = (double)row[reflect_idx(x + j, W)];
+                tmp = __dadd_rn(tmp, __dmul_rn(__dadd_rn(a, c), w[j]));
+            }
+        }
+        dst[i] = (float)tmp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// softmax over channels + unary = -log(clip(p, 1e-5, 1)), written pixel-major [n][K]
+// (densecrf's value layout).  include/pnp_math.h defines exp/log bit-exactly for host and device.
+__global__ void unary_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc, float* __restrict__ unary) {
+    const int b = blockIdx.y;
+    const PostDesc d = desc[b];
+    const int n = d.H * d.W, K = d.K;
+    const float* m = maps + d.off;
+    float* u = unary + d.off;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float mx = m[i];
+        for (int k = 1; k < K; k++) {
+            const float v = m[(size_t)k * n + i];
+            if (v > mx || v != v) mx = v;
+        }
+        float s = 0.f;
+        for (int k = 0; k < K; k++) s = __fadd_rn(s, pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)));
+        for (int k = 0; k < K; k++) {
+            float p = __fdiv_rn(pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)), s);
+            if (p < 1e-5f) p = 1e-5f;
+            else if (p > 1.0f) p = 1.0f;
+            u[(size_t)i * K + k] = -pnp_logf(p);
+        }
+    }
+}
+
+// argmax over channels.  layout_pixel_major: Q[n][K] (CRF marginals) else maps[K][n].
+// np.argmax semantics: first maximum, NaN counts as maximum.
+__global__ void argmax_kernel(const float* __restrict__ q, const PostDesc* __restrict__ desc, const int32_t* __restrict__ lut,
+                              int lut_stride, uint8_t* __restrict__ labels, const size_t* __restrict__ label_off,
+                              int pixel_major) {
+    const int b = blockIdx.y;
+    const PostDesc d = desc[b];
+    const int n = d.H * d.W, K = d.K;
+    const float* p = q + d.off;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        int best = 0;
+        float bv = pixel_major ? p[(size_t)i * K] : p[i];
+        for (int k = 1; k < K; k++) {
+            const float v = pixel_major ? p[(size_t)i * K + k] : p[(size_t)k * n + i];
+            if (bv == bv && (v > bv || v != v)) { best = k; bv = v; }
+        }
+        labels[label_off[b] + i] = (uint8_t)lut[b * lut_stride + best];
+    }
+}
+
+// confusion histogram: hist[n_class * gt + pred] += 1 for 0 <= gt < n_class  (PnP.py:1106-1112)
+__global__ void hist_kernel(const uint8_t* __restrict__ labels, const float* __restrict__ gt, const PostDesc* __restrict__ desc,
+                            const size_t* __restrict__ label_off, unsigned long long* __restrict__ hist, int n_class) {
+    const int b = blockIdx.y;
+    const PostDesc d = desc[b];
+    const int n = d.H * d.W;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float g = gt[label_off[b] + i];
+        if (g >= 0.f && g < (float)n_class) {
+            const int gi = (int)g, pi = labels[label_off[b] + i];
+            if (pi < n_class) atomicAdd(&hist[(size_t)gi * n_class + pi], 1ULL);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static inline int ok() { return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP; }
+
+int gradcam_gather(const float* P, const float* dP, const int64_t* mask, int ld_mask, float* out, int B, int nheads,
+                   int head, int L, int Nst, int PP, hipStream_t s) {
+    const int total = B * (L - 1) * PP;
+    if (total <= 0) return PNP_ERR_ARG;
+    hipLaunchKernelGGL(gradcam_gather_kernel, dim3((total + 255) / 256), dim3(256), 0, s, P, dP, mask, ld_mask, out, B,
+                       nheads, head, L, Nst, PP);
+    return ok();
+}
+
+int drop_step(const float* G, float* g0, float* agg, uint8_t* dropped, int32_t* picks, int iter, int B, int T, int PP,
+              int npick, int max_picks, hipStream_t s) {
+    if (PP * sizeof(float) > 48 * 1024) return PNP_ERR_ARG;
+    hipLaunchKernelGGL(drop_step_kernel, dim3(B), dim3(256), PP * sizeof(float), s, G, g0, agg, dropped, picks, iter, T,
+                       PP, npick, max_picks);
+    return ok();
+}
+
+int merge_tokens(const float* src, const int32_t* cls_off, const int32_t* tok_idx, const int32_t* cls_div,
+                 const int32_t* img_cls_off, float* out, int B, int T, int PP, int Cmax, hipStream_t s) {
+    hipLaunchKernelGGL(merge_tokens_kernel, dim3(Cmax, B), dim3(256), 0, s, src, cls_off, tok_idx, cls_div, img_cls_off,
+                       out, T, PP, Cmax);
+    return ok();
+}
+
+int threshold_maps(const float* merged, const int32_t* img_cls_off, float* out, float threshold, int B, int PP, int Cmax,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(threshold_kernel, dim3(Cmax, B), dim3(256), 0, s, merged, img_cls_off, out, threshold, PP, Cmax);
+    return ok();
+}
+
+int upsample_maps(const float* src, const PostDesc* desc, float* maps, int B, int P, int Cmax, int maxHW, hipStream_t s) {
+    const int nb = (maxHW + 255) / 256 < 64 ? (maxHW + 255) / 256 : 64;
+    hipLaunchKernelGGL(upsample_kernel, dim3(nb, Cmax, B), dim3(256), 0, s, src, desc, maps, P, Cmax);
+    return ok();
+}
+
+int minmax_normalize(float* maps, const PostDesc* desc, float* stats, int B, int Kmax, int maxHW, int class_channels_only,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(minmax_kernel, dim3(Kmax, B), dim3(256), 0, s, maps, desc, stats, Kmax, class_channels_only);
+    const int nb = (maxHW + 255) / 256 < 64 ? (maxHW + 255) / 256 : 64;
+    hipLaunchKernelGGL(normalize_kernel, dim3(nb, Kmax, B), dim3(256), 0, s, maps, desc, stats, Kmax, class_channels_only);
+    return ok();
+}
+
+int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipStream_t s) {
+    const int nb = (maxHW + 255) / 256 < 128 ? (maxHW + 255) / 256 : 128;
+    hipLaunchKernelGGL(background_kernel, dim3(nb, B), dim3(256), 0, s, maps, desc);
+    return ok();
+}
+
+int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
+              int B, int Kmax, int maxHW, hipStream_t s) {
+    const int nb = (maxHW + 255) / 256 < 128 ? (maxHW + 255) / 256 : 128;
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(nb, Kmax, B), dim3(256), 0, s, in, tmp, desc, wts, wt_off, 0);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(nb, Kmax, B), dim3(256), 0, s, tmp, out, desc, wts, wt_off, 1);
+    return ok();
+}
+
+int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, hipStream_t s) {
+    const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
+    hipLaunchKernelGGL(unary_kernel, dim3(nb, B), dim3(256), 0, s, maps, desc, unary);
+    return ok();
+}
+
+int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int lut_stride, uint8_t* labels,
+                 const size_t* label_off, int pixel_major, int B, int maxHW, hipStream_t s) {
+    const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
+    hipLaunchKernelGGL(argmax_kernel, dim3(nb, B), dim3(256), 0, s, q, desc, lut, lut_stride, labels, label_off, pixel_major);
+    return ok();
+}
+
+int confusion_hist(const uint8_t* labels, const float* gt, const PostDesc* desc, const size_t* label_off,
+                   unsigned long long* hist, int n_class, int B, int maxHW, hipStream_t s) {
+    const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
+    hipLaunchKernelGGL(hist_kernel, dim3(nb, B), dim3(256), 0, s, labels, gt, desc, label_off, hist, n_class);
+    return ok();
+}
+
+}  // namespace pnp

@@ -1,0 +1,276 @@
+// ViT-side kernels: patch gather (im2col with salience-dropped patches zeroed), cls/pos rows,
+// LayerNorm, and the fused patch self-attention (flash-style, MFMA QK^T / PV, LDS-staged K / V^T).
+// Reference: vit.py:274-290 (forward), :91-121 (Attention), :164-167 (Block);
+//            PnP_OVSS_0514_updated_segmentation.py:597-603 (zeroing dropped 16x16 blocks).
+#include "common.h"
+#include "kernels.h"
+
+namespace pnp {
+
+// ------------------------------------------------------------------------------------------
+// im2col for the 16x16/16 patch conv.  One thread per (patch row m, channel c, kernel row i):
+// reads 16 contiguous fp32 pixels, writes 16 T.  Patches flagged in `dropped` are written as
+// zeros: the reference zeroes those pixels in normalised space before the conv (PnP.py:602), so
+// their embedding is bias + pos only.
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ img, const uint8_t* __restrict__ dropped,
+                                T* __restrict__ out, int B, int S, int P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = B * P * P * 3 * 16;
+    if (idx >= total) return;
+    const int i = idx & 15;
+    const int c = (idx >> 4) % 3;
+    const int m = idx / 48;
+    const int b = m / (P * P), p = m - b * P * P;
+    const int py = p / P, px = p - py * P;
+    T* o = out + (size_t)m * 768 + c * 256 + i * 16;
+    const bool drop = dropped && dropped[m];
+    const float* src = img + (((size_t)b * 3 + c) * S + (py * 16 + i)) * S + px * 16;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        f32x4 x = drop ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(src + v * 4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[v * 4 + e] = from_f32<T>(x[e]);
+    }
+}
+
+__global__ void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                float* __restrict__ x, int B, int N, int D) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    const int b = idx / D, d = idx - b * D;
+    x[(size_t)b * N * D + d] = cls[d] + pos[d];
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (D <= 1024, D % 4 == 0): one wave per row, two-pass in registers.
+// Optional outputs: y (fp32), yt (T), xhat (fp32) and rstd (fp32 per row) for the backward.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float eps, int rows, int D,
+                                                        float* __restrict__ y, T* __restrict__ yt,
+                                                        float* __restrict__ xhat, float* __restrict__ rstd_out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    f32x4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = lane + i * 64;
+        v[i] = c < nv ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float d = v[i][e] - mean;
+                ss += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) / (float)D + eps);
+    if (rstd_out && lane == 0) rstd_out[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int c = lane + i * 64;
+        if (c >= nv) continue;
+        const f32x4 wv = reinterpret_cast<const f32x4*>(w)[c];
+        const f32x4 bv = reinterpret_cast<const f32x4*>(b)[c];
+        f32x4 h, o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            h[e] = (v[i][e] - mean) * rstd;
+            o[e] = h[e] * wv[e] + bv[e];
+        }
+        if (xhat) reinterpret_cast<f32x4*>(xhat + (size_t)row * D)[c] = h;
+        if (y) reinterpret_cast<f32x4*>(y + (size_t)row * D)[c] = o;
+        if (yt) {
+            T* p = yt + (size_t)row * D + c * 4;
+#pragma unroll
+            for (int e = 0; e < 4; e++) p[e] = from_f32<T>(o[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// ViT self-attention, head_dim 64, one workgroup = 64 query rows of one (image, head); each of the
+// 4 waves owns 16 queries.  Per 64-key tile: S^T = K.Q^T (key on the accumulator row, query on the
+// lane column) -> online softmax entirely per lane -> O^T += V^T.P^T with P taken straight from
+// the S^T accumulators.  N x N scores are never materialised (the reference does: vit.py:106-108).
+//   qk : [B*N, ld_qk]  (q of head h at column h*64, k at column D + h*64)
+//   vt : [D, ld_vt]    row h*64+d, column b*Npad + key   (V^T written by the transposed-V GEMM)
+//   ctx: [B*N, D]
+template <typename T>
+__global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qk, int ld_qk, int D,
+                                                       const T* __restrict__ vt, int ld_vt, int Npad,
+                                                       T* __restrict__ ctx, int N, float scale) {
+    constexpr int ROWB = 64 * Elem<T>::kBytes;
+    constexpr int CPR = ROWB / 16;                 // 16-byte chunks per LDS row
+    constexpr int CPT = 64 * CPR / 256;            // chunks per thread per tile
+    __shared__ __attribute__((aligned(16))) char Ks[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) char Vs[64 * ROWB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const size_t row0 = (size_t)b * N;
+
+    int qrow = q0 + wave * 16 + r;
+    const bool q_valid = qrow < N;
+    qrow = q_valid ? qrow : N - 1;
+    Frag<T> fq[2];
+    {
+        const T* qp = qk + (row0 + qrow) * ld_qk + h * 64;
+        glb_frag(fq[0], qp, 0, q);
+        glb_frag(fq[1], qp, 1, q);
+    }
+    f32x4 acc_o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) acc_o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (N + 63) / 64;
+    chunk16 rk[CPT], rv[CPT];
+#define PNP_LOAD_TILE(t)                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < CPT; i++) {                                                          \
+        const int ci = tid + i * 256, row = ci / CPR, c = ci % CPR;                                            \
+        int key = (t) * 64 + row;                                                                              \
+        key = key < N ? key : N - 1;                                                                           \
+        rk[i] = *reinterpret_cast<const chunk16*>(                                                             \
+            reinterpret_cast<const char*>(qk + (row0 + key) * ld_qk + D + h * 64) + c * 16);                   \
+        rv[i] = *reinterpret_cast<const chunk16*>(                                                             \
+            reinterpret_cast<const char*>(vt + (size_t)(h * 64 + row) * ld_vt + (size_t)b * Npad + (t) * 64) + \
+            c * 16);                                                                                           \
+    }
+    PNP_LOAD_TILE(0)
+    for (int t = 0; t < ntiles; t++) {
+        if (t > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CPT; i++) {
+            const int ci = tid + i * 256, row = ci / CPR, c = ci % CPR;
+            *reinterpret_cast<chunk16*>(Ks + lds_off<ROWB>(row, c)) = rk[i];
+            *reinterpret_cast<chunk16*>(Vs + lds_off<ROWB>(row, c)) = rv[i];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) { PNP_LOAD_TILE(t + 1) }
+
+        // S^T tiles: rows = keys (kt*16 + 4q + e), col = query r
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                Frag<T> fk;
+                lds_frag<ROWB>(fk, Ks, kt * 16 + r, ks, q);
+                mma16(s[kt], fk, fq[ks]);
+            }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int key = t * 64 + kt * 16 + q * 4 + e;
+                const float v = key < N ? s[kt][e] * scale : -INFINITY;
+                s[kt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float p = __expf(s[kt][e] - m_new);
+                s[kt][e] = p;
+                ls += p;
+            }
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc_o[i] *= alpha;
+        // O^T += V^T . P^T
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            Frag<T> fp;
+            pack_p(fp, s[2 * u], s[2 * u + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                Frag<T> fv;
+                lds_frag_acc_order<ROWB>(fv, Vs, dt * 16 + r, u, q);
+                mma16(acc_o[dt], fv, fp);
+            }
+        }
+    }
+#undef PNP_LOAD_TILE
+    if (q_valid) {
+        const float inv = 1.0f / l_run;
+        T* o = ctx + (row0 + qrow) * D + h * 64 + q * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 pk = {(bf16)(acc_o[dt][0] * inv), (bf16)(acc_o[dt][1] * inv), (bf16)(acc_o[dt][2] * inv),
+                             (bf16)(acc_o[dt][3] * inv)};
+                *reinterpret_cast<bf16x4*>(o + dt * 16) = pk;
+            } else {
+                f32x4 ov = acc_o[dt] * inv;
+                *reinterpret_cast<f32x4*>(o + dt * 16) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <typename T>
+static int vit_attn_t(const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
+                      int H, int N, float scale, hipStream_t s) {
+    dim3 grid((N + 63) / 64, H, B);
+    hipLaunchKernelGGL((vit_attn_kernel<T>), grid, dim3(256), 0, s, (const T*)qk, ld_qk, D, (const T*)vt, ld_vt,
+                       Npad, (T*)ctx, N, scale);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
+                  int H, int N, float scale, hipStream_t s) {
+    if (D != H * 64 || Npad % 64 || Npad < N) return PNP_ERR_ARG;
+    return bf ? vit_attn_t<bf16>(qk, ld_qk, D, vt, ld_vt, Npad, ctx, B, H, N, scale, s)
+              : vit_attn_t<float>(qk, ld_qk, D, vt, ld_vt, Npad, ctx, B, H, N, scale, s);
+}
+
+int patchify(int bf, const float* img, const uint8_t* dropped, void* out, int B, int S, int P, hipStream_t s) {
+    const int total = B * P * P * 48;
+    const int nb = (total + 255) / 256;
+    if (bf) hipLaunchKernelGGL((patchify_kernel<bf16>), dim3(nb), dim3(256), 0, s, img, dropped, (bf16*)out, B, S, P);
+    else hipLaunchKernelGGL((patchify_kernel<float>), dim3(nb), dim3(256), 0, s, img, dropped, (float*)out, B, S, P);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+int cls_rows(const float* cls, const float* pos, float* x, int B, int N, int D, hipStream_t s) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, s, cls, pos, x, B, N, D);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+int layernorm(int bf, const float* x, const float* w, const float* b, float eps, int rows, int D, float* y, void* yt,
+              float* xhat, float* rstd, hipStream_t s) {
+    if (D > 1024 || D % 4) return PNP_ERR_ARG;
+    const int nb = (rows + 3) / 4;
+    if (bf) hipLaunchKernelGGL((layernorm_kernel<bf16>), dim3(nb), dim3(256), 0, s, x, w, b, eps, rows, D, y, (bf16*)yt, xhat, rstd);
+    else hipLaunchKernelGGL((layernorm_kernel<float>), dim3(nb), dim3(256), 0, s, x, w, b, eps, rows, D, y, (float*)yt, xhat, rstd);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+}  // namespace pnp

@@ -1,0 +1,334 @@
+"""ctypes binding of libpnp_hip.so (include/pnp_hip.h) + a thin `Engine` wrapper.
+
+PyTorch is plumbing here: it owns the device buffers handed to the C ABI (tensor.data_ptr()) and
+the current HIP stream.  There is NO fallback: if the library is missing or a call fails this
+module raises -- the product path never silently runs on the CPU or in eager PyTorch.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpnp_hip.so")
+
+
+class PnpConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("img_size", "patch", "vit_dim", "vit_depth", "vit_heads", "vit_mlp_ratio")] + \
+               [("vit_ln_eps", C.c_float)] + \
+               [(n, C.c_int32) for n in ("txt_hidden", "txt_layers", "txt_heads", "txt_inter")] + \
+               [("txt_ln_eps", C.c_float)] + \
+               [(n, C.c_int32) for n in ("vocab", "max_pos", "enc_token_id", "max_batch", "max_text_len",
+                                         "stash_layer", "compute_bf16", "device")]
+
+
+class PnpPostBatch(C.Structure):
+    _fields_ = [("B", C.c_int32),
+                ("H", C.POINTER(C.c_int32)), ("W", C.POINTER(C.c_int32)),
+                ("n_classes", C.POINTER(C.c_int32)), ("has_bg", C.POINTER(C.c_int32)),
+                ("img_cls_off", C.POINTER(C.c_int32)), ("cls_off", C.POINTER(C.c_int32)),
+                ("tok_idx", C.POINTER(C.c_int32)), ("cls_div", C.POINTER(C.c_int32)),
+                ("lut", C.POINTER(C.c_int32)), ("lut_stride", C.c_int32),
+                ("d_rgb", C.c_void_p), ("d_gt", C.c_void_p),
+                ("blur_wts", C.POINTER(C.c_double)), ("blur_wt_off", C.POINTER(C.c_int32))]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"or `make -C pnp-ovss_amd/csrc` (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "pnp_create": (i32, [C.POINTER(PnpConfig), C.POINTER(vp)]),
+        "pnp_destroy": (None, [vp]),
+        "pnp_last_error": (C.c_char_p, [vp]),
+        "pnp_workspace_bytes": (C.c_size_t, [C.POINTER(PnpConfig)]),
+        "pnp_load_weight": (i32, [vp, C.c_char_p, vp, C.POINTER(i64), i32, i32]),
+        "pnp_finalize_weights": (i32, [vp]),
+        "pnp_vit_forward": (i32, [vp, vp, vp, i32, vp]),
+        "pnp_text_forward_xattn": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+        "pnp_xattn_grad": (i32, [vp, i32, i32, vp]),
+        "pnp_gradcam_gather": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+        "pnp_compute_gradcam": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+        "pnp_drop_step": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "pnp_drop_loop": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+        "pnp_post_reserve": (i32, [vp, i32, i64, i32, i32, i32]),
+        "pnp_post_prepare": (i32, [vp, C.POINTER(PnpPostBatch), i32, vp]),
+        "pnp_merge_tokens": (i32, [vp, vp, i32, vp]),
+        "pnp_threshold_upsample": (i32, [vp, f32, i32, vp]),
+        "pnp_blur_minmax": (i32, [vp, vp]),
+        "pnp_densecrf": (i32, [vp, i32, f32, f32, f32, f32, f32, vp]),
+        "pnp_remap_hist": (i32, [vp, i32, vp, vp, i32, vp]),
+        "pnp_postprocess": (i32, [vp, vp, i32, f32, i32, i32, vp, vp, i32, vp]),
+        "pnp_get_buffer": (i32, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "pnp_op_gemm": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
+        "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
+        "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI drift, fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes", "pnp_load_weight",
+            "pnp_finalize_weights", "pnp_vit_forward", "pnp_text_forward_xattn", "pnp_xattn_grad",
+            "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
+            "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
+            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_op_gemm", "pnp_op_layernorm", "pnp_op_cast"]
+
+
+class _DevView:
+    """Expose a raw device pointer to torch through __cuda_array_interface__."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def gaussian_taps(H, W, scale=0.05, truncate=4.0):
+    """scipy.ndimage._filters._gaussian_kernel1d (order 0) for sigma = scale * max(H, W)
+    (PnP_OVSS_0514_updated_segmentation.py:1150) -> taps at distance 0..radius (float64)."""
+    sigma = scale * max(H, W)
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    phi = phi / phi.sum()
+    return np.ascontiguousarray(phi[radius:][: radius + 1])
+
+
+class Engine:
+    """One libpnp_hip engine on one GPU."""
+
+    def __init__(self, cfg, max_batch, max_text_len=64, stash_layer=7, bf16=True, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("pnp_ovss.hip.Engine needs a HIP device (no CPU fallback)")
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self.bf16 = bool(bf16)
+        self.max_batch, self.max_text_len, self.stash_layer = max_batch, max_text_len, stash_layer
+        c = PnpConfig(cfg.img_size, cfg.patch, cfg.vit_dim, cfg.vit_depth, cfg.vit_heads, cfg.vit_mlp_ratio,
+                      cfg.vit_ln_eps, cfg.txt_hidden, cfg.txt_layers, cfg.txt_heads, cfg.txt_inter, cfg.txt_ln_eps,
+                      cfg.vocab, cfg.max_pos, cfg.enc_token_id, max_batch, max_text_len, stash_layer,
+                      1 if bf16 else 0, device)
+        self._c = c
+        self.h = C.c_void_p()
+        torch.cuda.set_device(device)
+        r = self.lib.pnp_create(C.byref(c), C.byref(self.h))
+        if r != 0:
+            msg = self.lib.pnp_last_error(self.h).decode() if self.h else "?"
+            raise RuntimeError(f"pnp_create failed ({r}): {msg}")
+        self._keep = []
+
+    # ------------------------------------------------------------------ plumbing
+    def _chk(self, r, what):
+        if r != 0:
+            raise RuntimeError(f"{what} failed ({r}): {self.lib.pnp_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            torch.cuda.synchronize()
+            self.lib.pnp_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def grid(self):
+        return self.cfg.grid
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd, finalize=True):
+        """sd: name -> numpy fp32 array or torch tensor (CPU, or CUDA e.g. after an RCCL broadcast)."""
+        for name, w in sd.items():
+            if isinstance(w, torch.Tensor):
+                t = w.detach().to(torch.float32).contiguous()
+                shape = (C.c_int64 * t.dim())(*t.shape)
+                r = self.lib.pnp_load_weight(self.h, name.encode(), C.c_void_p(t.data_ptr()), shape, t.dim(),
+                                             1 if t.is_cuda else 0)
+            else:
+                a = np.ascontiguousarray(w, dtype=np.float32)
+                shape = (C.c_int64 * a.ndim)(*a.shape)
+                r = self.lib.pnp_load_weight(self.h, name.encode(), C.c_void_p(a.ctypes.data), shape, a.ndim, 0)
+            self._chk(r, f"pnp_load_weight({name})")
+        if finalize:
+            self._chk(self.lib.pnp_finalize_weights(self.h), "pnp_finalize_weights")
+
+    # ------------------------------------------------------------------ model
+    def vit_forward(self, images, dropped=None):
+        B = images.shape[0]
+        self._chk(self.lib.pnp_vit_forward(self.h, _ptr(images), _ptr(dropped), B, _stream()), "pnp_vit_forward")
+
+    def text_forward(self, ids, mask, L):
+        B, ld = ids.shape
+        logits = torch.empty(B, 2, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.pnp_text_forward_xattn(self.h, _ptr(ids), _ptr(mask), ld, B, L, _ptr(logits), _stream()),
+                  "pnp_text_forward_xattn")
+        return logits
+
+    def xattn_grad(self, B, L):
+        self._chk(self.lib.pnp_xattn_grad(self.h, B, L, _stream()), "pnp_xattn_grad")
+
+    def gradcam_gather(self, mask, L, head):
+        B, ld = mask.shape
+        out = torch.empty(B, L - 1, self.grid, self.grid, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.pnp_gradcam_gather(self.h, _ptr(mask), ld, B, L, head, _ptr(out), _stream()),
+                  "pnp_gradcam_gather")
+        return out
+
+    def compute_gradcam(self, images, ids, mask, L, head, dropped=None):
+        B, ld = ids.shape
+        out = torch.empty(B, L - 1, self.grid, self.grid, device=self.device, dtype=torch.float32)
+        logits = torch.empty(B, 2, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.pnp_compute_gradcam(self.h, _ptr(images), _ptr(dropped), _ptr(ids), _ptr(mask), ld, B, L,
+                                               head, _ptr(out), _ptr(logits), _stream()), "pnp_compute_gradcam")
+        return out, logits
+
+    def drop_loop(self, images, ids, mask, L, head, drop_iter, npick=10):
+        B, ld = ids.shape
+        g0 = torch.empty(B, L - 1, self.grid, self.grid, device=self.device, dtype=torch.float32)
+        agg = torch.empty_like(g0) if drop_iter > 1 else None
+        picks = torch.full((B, max(drop_iter, 1) * npick), -1, device=self.device, dtype=torch.int32)
+        logits = torch.empty(B, 2, device=self.device, dtype=torch.float32)
+        self._chk(self.lib.pnp_drop_loop(self.h, _ptr(images), _ptr(ids), _ptr(mask), ld, B, L, head, drop_iter, npick,
+                                         _ptr(g0), _ptr(agg), _ptr(picks), _ptr(logits), _stream()), "pnp_drop_loop")
+        return g0, agg, picks, logits
+
+    # ------------------------------------------------------------------ post-process
+    def post_reserve(self, max_batch, max_total_pixels, max_pixels_per_image, max_channels, crf_chunk=0):
+        self._chk(self.lib.pnp_post_reserve(self.h, max_batch, int(max_total_pixels), int(max_pixels_per_image),
+                                            max_channels, crf_chunk), "pnp_post_reserve")
+
+    def post_prepare(self, sizes, plans, luts, has_bg, rgb=None, gt=None, want_crf=True):
+        """sizes: [(H, W)], plans: per image list of (token index list, divisor) per class,
+        luts: per image list mapping argmax index -> class id, rgb/gt: concatenated device tensors."""
+        B = len(sizes)
+        H = np.array([s[0] for s in sizes], dtype=np.int32)
+        W = np.array([s[1] for s in sizes], dtype=np.int32)
+        ncls = np.array([len(p) for p in plans], dtype=np.int32)
+        hb = np.array([1 if b else 0 for b in has_bg], dtype=np.int32)
+        img_cls_off = np.zeros(B + 1, dtype=np.int32)
+        img_cls_off[1:] = np.cumsum(ncls)
+        cls_off, tok_idx, cls_div = [0], [], []
+        for p in plans:
+            for toks, div in p:
+                tok_idx.extend(int(t) for t in toks)
+                cls_off.append(len(tok_idx))
+                cls_div.append(int(div))
+        cls_off = np.array(cls_off, dtype=np.int32)
+        tok_idx = np.array(tok_idx or [0], dtype=np.int32)
+        cls_div = np.array(cls_div or [1], dtype=np.int32)
+        stride = int(max(len(l) for l in luts))
+        lut = np.zeros((B, stride), dtype=np.int32)
+        for i, l in enumerate(luts):
+            lut[i, : len(l)] = l
+        taps = [gaussian_taps(h, w) for h, w in sizes]
+        wt_off = np.zeros(B + 1, dtype=np.int32)
+        wt_off[1:] = np.cumsum([len(t) for t in taps])
+        wts = np.ascontiguousarray(np.concatenate(taps), dtype=np.float64)
+        pb = PnpPostBatch(B, _i32p(H), _i32p(W), _i32p(ncls), _i32p(hb), _i32p(img_cls_off), _i32p(cls_off),
+                          _i32p(tok_idx), _i32p(cls_div), _i32p(lut), stride,
+                          C.c_void_p(rgb.data_ptr()) if rgb is not None else None,
+                          C.c_void_p(gt.data_ptr()) if gt is not None else None,
+                          wts.ctypes.data_as(C.POINTER(C.c_double)), _i32p(wt_off))
+        self._post_keep = (rgb, gt)          # the engine keeps the device pointers for the batch
+        self._post_sizes = list(sizes)
+        self._post_K = [int(n + b) for n, b in zip(ncls, hb)]
+        self._chk(self.lib.pnp_post_prepare(self.h, C.byref(pb), 1 if want_crf else 0, _stream()), "pnp_post_prepare")
+
+    def merge_tokens(self, gradcam):
+        T = gradcam.shape[1]
+        self._chk(self.lib.pnp_merge_tokens(self.h, _ptr(gradcam), T, _stream()), "pnp_merge_tokens")
+
+    def threshold_upsample(self, threshold, scale01):
+        self._chk(self.lib.pnp_threshold_upsample(self.h, float(threshold), 1 if scale01 else 0, _stream()),
+                  "pnp_threshold_upsample")
+
+    def blur_minmax(self):
+        self._chk(self.lib.pnp_blur_minmax(self.h, _stream()), "pnp_blur_minmax")
+
+    def densecrf(self, iters=10, pos_w=7.0, pos_xy=3.0, bi_w=10.0, bi_xy=50.0, bi_rgb=5.0):
+        self._chk(self.lib.pnp_densecrf(self.h, iters, pos_w, pos_xy, bi_w, bi_xy, bi_rgb, _stream()), "pnp_densecrf")
+
+    def remap_hist(self, from_crf, n_class=0, hist=None):
+        total = sum(h * w for h, w in self._post_sizes)
+        labels = torch.empty(total, device=self.device, dtype=torch.uint8)
+        self._chk(self.lib.pnp_remap_hist(self.h, 1 if from_crf else 0, _ptr(labels), _ptr(hist), n_class, _stream()),
+                  "pnp_remap_hist")
+        return labels
+
+    def postprocess(self, gradcam, threshold, scale01, mode, n_class=0, hist=None):
+        """mode: 'blur+crf' | 'crf' | 'blur' | None  (--postprocess, PnP.py:103)."""
+        m = 0
+        if mode:
+            m = (1 if "blur" in mode else 0) | (2 if "crf" in mode else 0)
+        total = sum(h * w for h, w in self._post_sizes)
+        labels = torch.empty(total, device=self.device, dtype=torch.uint8)
+        self._chk(self.lib.pnp_postprocess(self.h, _ptr(gradcam), gradcam.shape[1], float(threshold),
+                                           1 if scale01 else 0, m, _ptr(labels), _ptr(hist), n_class, _stream()),
+                  "pnp_postprocess")
+        return labels
+
+    def split_labels(self, labels):
+        out, o = [], 0
+        for h, w in self._post_sizes:
+            out.append(labels[o:o + h * w].view(h, w))
+            o += h * w
+        return out
+
+    # ------------------------------------------------------------------ introspection
+    def buffer(self, name, dtype=torch.float32):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.pnp_get_buffer(self.h, name.encode(), C.byref(p), C.byref(n)), f"pnp_get_buffer({name})")
+        item = torch.empty(0, dtype=dtype).element_size()
+        typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
+        return torch.as_tensor(_DevView(p.value, (n.value // item,), typestr), device=self.device)
+
+    def post_maps(self, name="maps"):
+        """Per-image (K,H,W) views of an internal post-process map buffer."""
+        flat = self.buffer(name)
+        out, o = [], 0
+        for (h, w), k in zip(self._post_sizes, self._post_K):
+            out.append(flat[o:o + k * h * w].view(k, h, w))
+            o += k * h * w
+        return out
+
+    def post_q(self):
+        """Per-image CRF marginals, pixel-major (H*W, K)."""
+        flat = self.buffer("crf_q")
+        out, o = [], 0
+        for (h, w), k in zip(self._post_sizes, self._post_K):
+            out.append(flat[o:o + k * h * w].view(h * w, k))
+            o += k * h * w
+        return out

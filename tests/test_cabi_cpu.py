@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads and exports every symbol include/pnp_hip.h declares (no compute
+calls without a GPU), and the host-side argument validation that needs no device works."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "pnp-ovss_amd", "pnp_ovss", "libpnp_hip.so")
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pnp_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pnp_[a-z_0-9]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "pnp-ovss_amd", "csrc"), "-j8"])
+    return ctypes.CDLL(LIB)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/pnp_hip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    from pnp_ovss import hip
+    assert sorted(hip.EXPORTED) == _declared()
+
+
+def test_workspace_bytes_is_host_only(lib):
+    from pnp_ovss import hip, config as C
+    cfg = C.blip_itm_large(336)
+    c = hip.PnpConfig(cfg.img_size, cfg.patch, cfg.vit_dim, cfg.vit_depth, cfg.vit_heads, cfg.vit_mlp_ratio,
+                      cfg.vit_ln_eps, cfg.txt_hidden, cfg.txt_layers, cfg.txt_heads, cfg.txt_inter, cfg.txt_ln_eps,
+                      cfg.vocab, cfg.max_pos, cfg.enc_token_id, 35, 32, 7, 1, 0)
+    lib.pnp_workspace_bytes.restype = ctypes.c_size_t
+    n = lib.pnp_workspace_bytes(ctypes.byref(c))
+    assert 1 << 30 < n < 64 << 30          # a few GB for batch 35 at 336^2; far below 288 GB HBM
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pnp_ovss import hip, config as C
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        hip.Engine(C.blip_itm_small(64), max_batch=1)
+
+
+def test_null_engine_calls_return_errors(lib):
+    lib.pnp_vit_forward.restype = ctypes.c_int32
+    assert lib.pnp_vit_forward(None, None, None, 1, None) != 0
+    lib.pnp_last_error.restype = ctypes.c_char_p
+    assert lib.pnp_last_error(None) == b"null engine"

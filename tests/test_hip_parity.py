@@ -1,0 +1,371 @@
+"""GPU parity tests: the HIP path (through the C ABI, via pnp_ovss.hip) against the CPU oracle on the
+same seeded inputs, and against the golden vectors produced by the reference itself.
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from pnp_ovss import config as C, synth            # noqa: E402
+from pnp_ovss.tokenizer import SynthTokenizer      # noqa: E402
+from oracle import blip_itm_np as OM               # noqa: E402
+from oracle import pipeline_np as OP               # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+_ENG = {}
+
+
+def _engine(cfg, seed, bf16, max_batch=4, max_text_len=32):
+    from pnp_ovss.hip import Engine
+    key = (cfg, seed, bf16, max_batch, max_text_len)
+    if key not in _ENG:
+        e = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len, stash_layer=7, bf16=bf16)
+        e.load_state_dict(synth.synth_state_dict(cfg, seed))
+        _ENG.clear()                       # keep one engine alive at a time (device memory)
+        _ENG[key] = e
+    return _ENG[key]
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def _golden(name):
+    here = os.path.dirname(os.path.abspath(__file__))
+    return np.load(os.path.join(here, "golden", name), allow_pickle=False)
+
+
+def _cfg(g):
+    return C.ModelCfg(**json.loads(str(g["cfg"])))
+
+
+def _norm01(m):
+    m = m.astype(np.float64)
+    lo = m.min(axis=(-1, -2), keepdims=True)
+    hi = m.max(axis=(-1, -2), keepdims=True)
+    return (m - lo) / np.maximum(hi - lo, 1e-30)
+
+
+# ------------------------------------------------------------------------------------------ operators
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (2048, 1536, 256), (77, 64, 1024)])
+def test_gemm(bf16, shape):
+    from pnp_ovss import hip
+    lib = hip.load_library()
+    M, N, K = shape
+    rng = np.random.default_rng(M + N)
+    A = rng.standard_normal((M, K), dtype=np.float32)
+    B = rng.standard_normal((N, K), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    resid = rng.standard_normal((M, N), dtype=np.float32)
+    dA, dB, dbias, dres = _dev(A), _dev(B), _dev(bias), _dev(resid)
+    out = torch.zeros(M, N, device="cuda")
+    if bf16:
+        tA = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+        tB = torch.empty(N, K, device="cuda", dtype=torch.bfloat16)
+        assert lib.pnp_op_cast(1, dA.data_ptr(), tA.data_ptr(), M * K, None) == 0
+        assert lib.pnp_op_cast(1, dB.data_ptr(), tB.data_ptr(), N * K, None) == 0
+        A = tA.float().cpu().numpy()
+        B = tB.float().cpu().numpy()
+        pa, pb = tA, tB
+    else:
+        pa, pb = dA, dB
+    r = lib.pnp_op_gemm(1 if bf16 else 0, pa.data_ptr(), K, pb.data_ptr(), K, M, N, K, dbias.data_ptr(), dres.data_ptr(),
+                        N, out.data_ptr(), N, 0, None)
+    assert r == 0
+    torch.cuda.synchronize()
+    ref = A.astype(np.float64) @ B.astype(np.float64).T + bias + resid
+    err = np.abs(out.cpu().numpy() - ref).max()
+    assert err < (2e-3 if bf16 else 2e-4) * np.sqrt(K / 128), err      # exact products, fp32 accumulation order only
+
+
+def test_layernorm():
+    from pnp_ovss import hip
+    lib = hip.load_library()
+    rng = np.random.default_rng(1)
+    for rows, D in [(37, 768), (130, 1024), (9, 128)]:
+        x = rng.standard_normal((rows, D), dtype=np.float32) * 3 + 1
+        w = rng.standard_normal(D, dtype=np.float32)
+        b = rng.standard_normal(D, dtype=np.float32)
+        dx, dw, db = _dev(x), _dev(w), _dev(b)
+        y = torch.empty(rows, D, device="cuda")
+        assert lib.pnp_op_layernorm(dx.data_ptr(), dw.data_ptr(), db.data_ptr(), 1e-6, rows, D, y.data_ptr(), None) == 0
+        ref, _, _ = OM.layer_norm(x, w, b, 1e-6)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=0, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------ model
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_vit_forward_small(bf16):
+    cfg = C.blip_itm_small(64)
+    W = synth.synth_state_dict(cfg, 3)
+    _, imgs = synth.synth_images(3, cfg.img_size, seed=5)
+    e = _engine(cfg, 3, bf16)
+    e.vit_forward(_dev(imgs))
+    torch.cuda.synchronize()
+    got = e.buffer("image_embeds")[: 3 * cfg.n_img_tokens * cfg.vit_dim].view(3, cfg.n_img_tokens, cfg.vit_dim).cpu().numpy()
+    ref = OM.vit_forward(W, cfg, imgs)
+    err = np.abs(got - ref).max()
+    assert err < (0.15 if bf16 else 2e-4), err
+    if bf16:
+        assert np.abs(got - ref).mean() < 0.02
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gradcam_small_vs_reference_golden(bf16):
+    g = _golden("gradcam_small.npz")
+    cfg = _cfg(g)
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=int(g["image_seed"]))
+    e = _engine(cfg, int(g["weight_seed"]), bf16)
+    ids, mask = _dev(g["input_ids"]), _dev(g["attention_mask"])
+    L = int(g["attention_mask"].sum(1).max())
+    ref_maps = g["maps"]                       # (layer, head, B, L-1, P, P)
+    for head in (9, 0):
+        out, logits = e.compute_gradcam(_dev(imgs), ids, mask, L, head)
+        torch.cuda.synchronize()
+        got, ref = out.cpu().numpy(), ref_maps[7, head]
+        if not bf16:
+            np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-3)
+            assert np.abs(got - ref).max() < 1e-4          # north_star: float saliency maps within 1e-4 max-abs
+            assert np.abs(_norm01(got) - _norm01(ref)).max() < 2e-3
+        else:
+            assert np.abs(got - ref).max() < 0.05 * ref.max() + 1e-4
+            assert np.abs(_norm01(got) - _norm01(ref)).mean() < 0.02
+    if not bf16:
+        # stash layout: (B, heads, L, Nst) with the call's B and L, Nst = 64-padded image tokens
+        P = e.buffer("P")[: 2 * 12 * L * 64].view(2, 12, L, 64)[..., : cfg.n_img_tokens].cpu().numpy()
+        dP = e.buffer("dP")[: 2 * 12 * L * 64].view(2, 12, L, 64)[..., : cfg.n_img_tokens].cpu().numpy()
+        np.testing.assert_allclose(P, g["P7"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(dP, g["dP7"], rtol=0, atol=3e-4)
+
+
+def test_gradcam_buffers_layout_note():
+    """P / dP stash rows are (B, heads, L, Nst) with L the *call's* L, not max_text_len."""
+    cfg = C.blip_itm_small(64)
+    e = _engine(cfg, 3, False)
+    assert e.cfg.n_img_tokens == 17
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_drop_loop_small_vs_reference_golden(bf16):
+    g = _golden("droploop_small.npz")
+    cfg = _cfg(g)
+    _, imgs = synth.synth_images(3, cfg.img_size, seed=int(g["image_seed"]))
+    e = _engine(cfg, int(g["weight_seed"]), bf16)
+    ids, mask = _dev(g["input_ids"]), _dev(g["attention_mask"])
+    L = int(g["attention_mask"].sum(1).max())
+    g0, agg, picks, _ = e.drop_loop(_dev(imgs), ids, mask, L, 9, 4)
+    torch.cuda.synchronize()
+    picks = picks.cpu().numpy()
+    zeroed = g["zeroed_d4"]                    # (iter, B, PP): patches the reference had zeroed BEFORE iteration k
+    same = 0
+    for it in range(1, 4):
+        for b in range(3):
+            ref_set = set(np.nonzero(zeroed[it, b])[0])
+            same += ref_set == set(picks[b, : it * 10].tolist())
+    if not bf16:
+        assert same == 9, f"pick sets differ from the reference in {9 - same} of 9 (iteration, image) pairs"
+        np.testing.assert_allclose(g0.cpu().numpy(), g["g0_d4"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(agg.cpu().numpy(), g["agg_d4"], rtol=0, atol=4e-4)
+    else:
+        assert same >= 3                        # bf16 may reorder near-ties; the first iteration must agree
+        assert np.abs(agg.cpu().numpy() - g["agg_d4"]).max() < 0.08 * g["agg_d4"].max()
+    g0_1, agg_1, _, _ = e.drop_loop(_dev(imgs), ids, mask, L, 9, 1)
+    assert agg_1 is None
+    if not bf16:
+        np.testing.assert_allclose(g0_1.cpu().numpy(), g["g0_d1"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_gradcam_large_336_vs_reference_golden(bf16):
+    """BLIP-ITM-large geometry at 336^2 (BASELINE config): the selected (layer 8, head 9) map."""
+    g = _golden("gradcam_large.npz")
+    cfg = _cfg(g)
+    _, imgs = synth.synth_images(1, 336, seed=int(g["image_seed"]))
+    ids, mask = synth.synth_tokens(cfg, [int(g["n_classes"])], seed=int(g["token_seed"]))
+    e = _engine(cfg, int(g["weight_seed"]), bf16, max_batch=2, max_text_len=32)
+    out, logits = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), 25, 9)
+    torch.cuda.synchronize()
+    got, ref = out.cpu().numpy(), g["map_7_9"]
+    if not bf16:
+        assert np.abs(got - ref).max() < 1e-4
+        assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < 5e-3
+        np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=2e-2)
+    else:
+        assert np.abs(got - ref).max() < 0.1 * ref.max()
+        assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).mean() < 0.03
+
+
+# ------------------------------------------------------------------------------------------ post-process
+
+def _post_case(seed=0):
+    """Seeded gradcam-like maps for 3 images with ragged captions / sizes / class counts."""
+    cfg = C.blip_itm_small(128)                # P = 8
+    rng = np.random.default_rng(seed)
+    tok = SynthTokenizer(cfg.vocab)
+    caps = ["A picture of cat pottedplant dog aeroplane", "A picture of bus tvmonitor", "A picture of person"]
+    classes = [c.split()[3:] for c in caps]
+    enc = tok(caps, padding="max_length", max_length=500)
+    ids, mask = enc.input_ids.numpy(), enc.attention_mask.numpy()
+    L = int(mask.sum(1).max())
+    pieces = [[tok.decode([t]) for t in ids[i][4:int(mask[i].sum()) - 1]] for i in range(3)]
+    maps = rng.random((3, L - 1, cfg.grid, cfg.grid), dtype=np.float32) ** 3
+    for b in range(3):                          # rows past the caption are masked to zero like the real gather
+        maps[b, int(mask[b].sum()) - 1:] = 0
+    sizes = [(90, 120), (128, 128), (75, 100)]
+    rgb = [np.clip(np.repeat(np.repeat(rng.integers(0, 256, size=((h + 7) // 8, (w + 7) // 8, 3)), 8, 0), 8, 1)[:h, :w]
+                   + rng.integers(-6, 7, size=(h, w, 3)), 0, 255).astype(np.uint8) for h, w in sizes]
+    best = [[7, 15, 11, 0], [5, 19], [14]]
+    gts = [rng.integers(0, 21, size=s).astype(np.float32) for s in sizes]
+    return cfg, maps, pieces, classes, sizes, rgb, best, gts
+
+
+def _plans(pieces, n_classes):
+    out = []
+    for pc, n in zip(pieces, n_classes):
+        plan = OP.merge_plan(pc, n)
+        out.append(plan if plan is not None else [([i], 1) for i in range(n)])
+    return out
+
+
+def _lut(best, has_bg, K):
+    """Fold the reference's in-place descending remap (PnP.py:390-399) into an index table."""
+    lab = np.arange(K, dtype=np.float32)
+    return [int(v) for v in OP.remap_labels(lab, best, has_bg)]
+
+
+@pytest.mark.parametrize("data_type,scale01", [("voc", True), ("voc", False), ("psc", False)])
+def test_postprocess_stages_bit_exact_vs_oracle(data_type, scale01):
+    cfg, maps, pieces, classes, sizes, rgb, best, gts = _post_case()
+    e = _engine(cfg, 4, False)
+    if not e.lib.pnp_get_buffer:                # pragma: no cover
+        pytest.skip()
+    B = 3
+    has_bg = [OP.has_background(data_type, len(b)) for b in best]
+    K = [len(b) + int(h) for b, h in zip(best, has_bg)]
+    if not getattr(e, "_reserved", False):
+        e.post_reserve(4, 4 * 128 * 128, 128 * 128, 8, 0)
+        e._reserved = True
+    d_rgb = _dev(np.concatenate([r.reshape(-1) for r in rgb]))
+    d_gt = _dev(np.concatenate([g.reshape(-1) for g in gts]))
+    e.post_prepare(sizes, _plans(pieces, [len(b) for b in best]), [_lut(b, h, k) for b, h, k in zip(best, has_bg, K)],
+                   has_bg, rgb=d_rgb, gt=d_gt, want_crf=True)
+    d_maps = _dev(maps)
+    e.merge_tokens(d_maps)
+    e.threshold_upsample(0.15, scale01)
+    torch.cuda.synchronize()
+    pre = [m.cpu().numpy() for m in e.post_maps("maps_pre_blur")]
+    ref_pre = []
+    for b in range(B):
+        merged = OP.merge_tokens(maps[b], pieces[b], len(best[b]))
+        ref_pre.append(OP.threshold_upsample(merged, sizes[b][0], sizes[b][1], 0.15, scale01, has_bg[b]))
+        np.testing.assert_array_equal(pre[b], ref_pre[b])                      # bit-exact
+    e.blur_minmax()
+    torch.cuda.synchronize()
+    blurred = [m.cpu().numpy() for m in e.post_maps("maps")]
+    ref_blur = []
+    for b in range(B):
+        rb = np.stack([OP.blurring(ref_pre[b][k], sizes[b]) for k in range(K[b])])
+        ref_blur.append(rb)
+        np.testing.assert_array_equal(blurred[b], rb)                           # bit-exact (scipy arithmetic)
+    # blur-only labels + histogram
+    hist = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    labels = e.split_labels(e.remap_hist(False, 21, hist))
+    torch.cuda.synchronize()
+    ref_labels = [OP.remap_labels(np.argmax(rb, axis=0).astype(np.float32), bst, h) for rb, bst, h in zip(ref_blur, best, has_bg)]
+    for b in range(B):
+        np.testing.assert_array_equal(labels[b].cpu().numpy().astype(np.float32), ref_labels[b])
+    _, ref_hist = OP.scores(gts, ref_labels, 21)
+    np.testing.assert_array_equal(hist.cpu().numpy().reshape(21, 21), ref_hist.astype(np.int64))
+    # dense CRF: label maps bit-exact vs the oracle's restatement, marginals to float tolerance
+    e.densecrf()
+    crf_labels = e.split_labels(e.remap_hist(True))
+    torch.cuda.synchronize()
+    qs = e.post_q()
+    for b in range(B):
+        lab, q, stats = OP.densecrf(rgb[b], ref_blur[b], want_q=True)
+        got_q = qs[b].cpu().numpy().T.reshape(K[b], *sizes[b])
+        np.testing.assert_allclose(got_q, q, rtol=0, atol=1e-6)
+        ref_l = OP.remap_labels(lab, best[b], has_bg[b])
+        np.testing.assert_array_equal(crf_labels[b].cpu().numpy().astype(np.float32), ref_l)
+    idb = e.buffer("crf_idbase_bilateral", torch.int32)[: B + 1].cpu().numpy()
+    for b in range(B):
+        _, _, stats = OP.densecrf(rgb[b], ref_blur[b], want_q=True, iters=0)
+        assert idb[b + 1] - idb[b] == stats[1]                                  # same number of lattice points
+
+
+def test_postprocess_nan_channel_semantics():
+    """An all-zero class map blurs to 0/0 = NaN (PnP.py:1151-1152); the reference's argmax then
+    returns that channel everywhere.  The device path must reproduce it (oracle is pinned on it)."""
+    cfg, maps, pieces, classes, sizes, rgb, best, gts = _post_case(seed=3)
+    maps = maps.copy()
+    maps[1, 3] = 0                                   # first class of image 1: constant map -> NaN after min-max
+    e = _engine(cfg, 4, False)
+    if not getattr(e, "_reserved", False):
+        e.post_reserve(4, 4 * 128 * 128, 128 * 128, 8, 0)
+        e._reserved = True
+    has_bg = [True, True, True]
+    K = [len(b) + 1 for b in best]
+    e.post_prepare(sizes, _plans(pieces, [len(b) for b in best]), [_lut(b, True, k) for b, k in zip(best, K)], has_bg,
+                   rgb=None, gt=None, want_crf=False)
+    labels = e.split_labels(e.postprocess(_dev(maps), 0.15, False, "blur"))
+    torch.cuda.synchronize()
+    for b in range(3):
+        merged = OP.merge_tokens(maps[b], pieces[b], len(best[b]))
+        with np.errstate(all="ignore"):
+            pre = OP.threshold_upsample(merged, sizes[b][0], sizes[b][1], 0.15, False, True)
+            lab = OP.postprocess("blur", pre, None, sizes[b])
+        np.testing.assert_array_equal(labels[b].cpu().numpy().astype(np.float32), OP.remap_labels(lab, best[b], True))
+
+
+def test_full_size_properties_336():
+    """Size-independent properties at the benchmark geometry (336^2, K = 21, blur + CRF)."""
+    cfg = C.blip_itm_large(336)
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    e = Engine(cfg, max_batch=2, max_text_len=32, stash_layer=7, bf16=True)
+    e.load_state_dict(synth.synth_state_dict(cfg, 0))
+    B = 2
+    rgb, imgs = synth.synth_images(B, 336, seed=1234)
+    ids, mask = synth.synth_tokens(cfg, [20, 20], seed=1234)
+    g0, agg, picks, _ = e.drop_loop(_dev(imgs), _dev(ids), _dev(mask), 25, 9, 4)
+    torch.cuda.synchronize()
+    pk = picks.cpu().numpy()
+    assert pk.min() >= 0 and pk.max() < cfg.grid ** 2
+    for b in range(B):
+        assert len(set(pk[b].tolist())) == 40             # 4 x 10 distinct patches while positives remain
+    a, z = agg.cpu().numpy(), g0.cpu().numpy()
+    assert np.isfinite(a).all() and (a >= 0).all() and (a + 1e-12 >= 2 * z - 1e-6).all()   # agg = 2*l0 + l1 + ...
+    for b in range(B):                                      # picked cells are zero in every later iteration's map
+        first = pk[b, :10]
+        rows, cols = first // cfg.grid, first % cfg.grid
+        np.testing.assert_allclose(a[b][:, rows, cols], 2 * z[b][:, rows, cols], rtol=0, atol=1e-7)
+    e.post_reserve(B, B * 336 * 336, 336 * 336, 21, 0)
+    plans = [[([i], 1) for i in range(20)]] * B
+    luts = [list(range(21))] * B
+    gt = np.random.default_rng(0).integers(0, 21, size=(B, 336, 336)).astype(np.float32)
+    e.post_prepare([(336, 336)] * B, plans, luts, [True] * B, rgb=_dev(rgb.reshape(-1)), gt=_dev(gt.reshape(-1)))
+    hist = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    labels = e.postprocess(agg, 0.15, False, "blur+crf", 21, hist)
+    torch.cuda.synchronize()
+    lab = labels.cpu().numpy()
+    assert lab.max() <= 20
+    h = hist.cpu().numpy().reshape(21, 21)
+    assert h.sum() == B * 336 * 336                         # every valid gt pixel counted once
+    np.testing.assert_array_equal(h.sum(0), np.bincount(lab, minlength=21))
+    q = torch.cat([x.reshape(-1, 21) for x in e.post_q()]).cpu().numpy()
+    np.testing.assert_allclose(q.sum(1), 1.0, atol=1e-4)    # marginals are distributions
+    labels2 = e.postprocess(agg, 0.15, False, "blur+crf")   # deterministic (sorted splat, no float atomics)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(labels2.cpu().numpy(), lab)
+    e.close()
