@@ -140,6 +140,12 @@ int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T, float thre
 /* Named internal device buffers: "image_embeds" (fp32 B*N*D), "maps" (fp32 post-process maps),
  * "crf_q", "P", "dP", "crf_M" (int32 [2][B+1] lattice id bases), ... */
 int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, size_t* bytes);
+/* Live kernel timing for bench.py's roofline line: while enabled, every launch of the dominant
+ * kernel (the 128x128-tile NT GEMM) is bracketed by hipEvents on the launch stream.  pnp_profile_read
+ * synchronises those events and returns launches, summed algorithmic FLOPs (2*M*N*K) and summed
+ * kernel milliseconds since the last enable.  Off by default (no events on the hot path). */
+int pnp_profile_enable(pnp_engine* e, int32_t on);
+int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms);
 /* Stand-alone operator entry points used by the parity tests (device pointers, see csrc/). */
 int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,
                 const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, int32_t gelu,

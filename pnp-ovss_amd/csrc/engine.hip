@@ -1122,6 +1122,32 @@ extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, siz
     return fail(e, PNP_ERR_ARG, "unknown buffer %s", name);
 }
 
+extern "C" int pnp_profile_enable(pnp_engine* e, int32_t on) {
+    if (!e) return PNP_ERR_ARG;
+    GemmProfile& pf = gemm_profile();
+    pf.on = on != 0;
+    pf.used = 0;
+    pf.launches = 0;
+    pf.flops = 0;
+    return PNP_OK;
+}
+
+extern "C" int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms) {
+    if (!e || !launches || !flops || !ms) return PNP_ERR_ARG;
+    GemmProfile& pf = gemm_profile();
+    double total = 0;
+    for (int i = 0; i < pf.used; i++) {
+        HIPCHK(e, hipEventSynchronize(pf.ev1[i]));
+        float t = 0;
+        HIPCHK(e, hipEventElapsedTime(&t, pf.ev0[i], pf.ev1[i]));
+        total += t;
+    }
+    *launches = pf.launches;
+    *flops = pf.flops;
+    *ms = total;
+    return PNP_OK;
+}
+
 extern "C" int pnp_op_gemm(int32_t bf, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,
                            int32_t K, const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo,
                            int32_t gelu, void* stream) {

@@ -28,4 +28,15 @@ struct GemmArgs {
 
 int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s);
 
+// Optional live timing of the big-tile GEMM launches (bench.py roofline): a ring of event pairs.
+struct GemmProfile {
+    bool on = false;
+    static constexpr int kMax = 8192;
+    hipEvent_t ev0[kMax], ev1[kMax];
+    int created = 0, used = 0;
+    long long launches = 0;
+    double flops = 0;
+};
+GemmProfile& gemm_profile();
+
 }  // namespace pnp

@@ -232,8 +232,31 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
         g.N = (g.N + 63) / 64 * 64;
         return dtype_bf16 ? launch_cfg<bf16, 64, 64>(g, s) : launch_cfg<float, 64, 64>(g, s);
     }
+    GemmProfile& pf = gemm_profile();
+    const bool timed = pf.on && pf.used < GemmProfile::kMax;
+    if (timed) {
+        while (pf.created <= pf.used) {
+            if (hipEventCreate(&pf.ev0[pf.created]) != hipSuccess || hipEventCreate(&pf.ev1[pf.created]) != hipSuccess)
+                return PNP_ERR_HIP;
+            pf.created++;
+        }
+        (void)hipEventRecord(pf.ev0[pf.used], s);
+    }
+    const double fl = 2.0 * g.M * (double)g.N * g.K;
     g.N = (g.N + 127) / 128 * 128;
-    return dtype_bf16 ? launch_cfg<bf16, 128, 128>(g, s) : launch_cfg<float, 128, 128>(g, s);
+    const int r = dtype_bf16 ? launch_cfg<bf16, 128, 128>(g, s) : launch_cfg<float, 128, 128>(g, s);
+    if (timed) {
+        (void)hipEventRecord(pf.ev1[pf.used], s);
+        pf.used++;
+        pf.launches++;
+        pf.flops += fl;
+    }
+    return r;
+}
+
+GemmProfile& gemm_profile() {
+    static GemmProfile p;
+    return p;
 }
 
 }  // namespace pnp

@@ -70,6 +70,8 @@ def load_library():
         "pnp_remap_hist": (i32, [vp, i32, vp, vp, i32, vp]),
         "pnp_postprocess": (i32, [vp, vp, i32, f32, i32, i32, vp, vp, i32, vp]),
         "pnp_get_buffer": (i32, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "pnp_profile_enable": (i32, [vp, i32]),
+        "pnp_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "pnp_op_gemm": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
         "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
         "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
@@ -86,7 +88,7 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_finalize_weights", "pnp_vit_forward", "pnp_text_forward_xattn", "pnp_xattn_grad",
             "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
-            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_op_gemm", "pnp_op_layernorm", "pnp_op_cast"]
+            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_layernorm", "pnp_op_cast"]
 
 
 class _DevView:
@@ -306,6 +308,15 @@ class Engine:
             out.append(labels[o:o + h * w].view(h, w))
             o += h * w
         return out
+
+    # ------------------------------------------------------------------ live kernel timing (bench roofline)
+    def profile_enable(self, on=True):
+        self._chk(self.lib.pnp_profile_enable(self.h, 1 if on else 0), "pnp_profile_enable")
+
+    def profile_read(self):
+        n, fl, ms = C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.pnp_profile_read(self.h, C.byref(n), C.byref(fl), C.byref(ms)), "pnp_profile_read")
+        return n.value, fl.value, ms.value
 
     # ------------------------------------------------------------------ introspection
     def buffer(self, name, dtype=torch.float32):
