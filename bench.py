@@ -32,6 +32,7 @@ import torch.distributed as dist  # noqa: E402
 N_CLASSES = 20
 IMG = 336
 LAYER, HEAD, DROP_ITER, THRESH = 7, 9, 4, 0.15
+NOISE = 4          # +-4 grey levels of per-pixel noise on the 8x8-block synthetic images (see synth.synth_images)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # /opt/skills/guides/MI355X_MICROARCH.md (dense)
 
 
@@ -42,7 +43,7 @@ def cpu_baseline(cfg, seed_w, n_images=1):
     from pnp_ovss import synth
     from oracle import pipeline_np as OP
     W = synth.synth_state_dict(cfg, seed_w)
-    rgb, imgs = synth.synth_images(n_images, IMG, seed=1234)
+    rgb, imgs = synth.synth_images(n_images, IMG, seed=1234, noise=NOISE)
     ids, mask = synth.synth_tokens(cfg, [N_CLASSES] * n_images, seed=1234)
     pieces = [[f"t{i}" for i in range(N_CLASSES)]] * n_images
     best = [list(range(N_CLASSES))] * n_images
@@ -106,7 +107,7 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- synthetic inputs, resident in HBM before the timed region (different images per rank)
-    rgb, imgs = synth.synth_images(B, IMG, seed=1234 + rank)
+    rgb, imgs = synth.synth_images(B, IMG, seed=1234 + rank, noise=NOISE)
     ids, mask = synth.synth_tokens(cfg, [N_CLASSES] * B, seed=1234 + rank)
     L = int(mask.sum(1).max())
     gt = np.random.default_rng(rank).integers(0, 21, size=(B, IMG, IMG)).astype(np.float32)

@@ -241,108 +241,207 @@ __global__ void neighbors_kernel(const uint64_t* __restrict__ ukeys, const int* 
 }
 
 // ------------------------------------------------------------------------------------------
-// splat: val[id, k] = sum over the lattice point's contributors (ascending pixel) of
-//        bary * (Q[pixel, k] * norm[pixel])          (Q == nullptr: the all-ones vector, K = 1)
-__global__ void crf_splat_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ Q,
-                                 const float* __restrict__ norm, float* __restrict__ val, int img0, int force_k1) {
-    const int b = img0 + blockIdx.y;
-    const PostDesc im = imgs[b];
-    const int K = force_k1 ? 1 : im.K;
+// Scalar (K = 1) lattice pass used once per batch for the normaliser: norm = 1/sqrt(L(1) + 1e-20).
+__global__ void crf_splat1_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, float* __restrict__ val) {
+    const int b = blockIdx.y;
     const int lo = L.idbase[b], hi = L.idbase[b + 1];
-    const size_t vbase = force_k1 ? (size_t)lo : im.voff[L.which] ;
-    const int total = (hi - lo) * K;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int idl = t / K, k = t - idl * K;
-        const int id = lo + idl;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < hi - lo; t += gridDim.x * blockDim.x) {
+        const int id = lo + t;
         const int e0 = L.seg_start[id], e1 = L.seg_start[id + 1];
         float acc = 0.f;
-        for (int e = e0; e < e1; e++) {
-            const uint32_t pv = L.vals[e];
-            const uint32_t pixel = pv / (uint32_t)L.D1;             // global pixel index
-            float in = 1.0f;
-            if (Q) in = Q[im.off + (size_t)(pixel - im.pix0) * K + k];
-            if (norm) in = __fmul_rn(in, norm[pixel]);
-            acc = __fadd_rn(acc, __fmul_rn(L.bary[pv], in));
+        for (int e = e0; e < e1; e++) acc = __fadd_rn(acc, L.bary[L.vals[e]]);
+        val[id] = acc;
+    }
+}
+
+__global__ void crf_blur1_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ src,
+                                 float* __restrict__ dst, int axis) {
+    const int b = blockIdx.y;
+    const int lo = L.idbase[b], hi = L.idbase[b + 1];
+    const int* n1 = L.n1 + (size_t)axis * L.cap;
+    const int* n2 = L.n2 + (size_t)axis * L.cap;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < hi - lo; t += gridDim.x * blockDim.x) {
+        const int id = lo + t;
+        const int a = n1[id], c = n2[id];
+        const float va = a >= 0 ? src[a] : 0.f;
+        const float vc = c >= 0 ? src[c] : 0.f;
+        dst[id] = (float)__dadd_rn((double)src[id], __dmul_rn(0.5, (double)__fadd_rn(va, vc)));
+    }
+}
+
+__global__ void crf_norm_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ val,
+                                float* __restrict__ norm_out, float alpha) {
+    const int b = blockIdx.y;
+    const PostDesc im = imgs[b];
+    const int n = im.H * im.W;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < n; pix += gridDim.x * blockDim.x) {
+        const size_t pv0 = (size_t)(im.pix0 + pix) * L.D1;
+        float out = 0.f;
+        for (int v = 0; v < L.D1; v++)
+            out = __fadd_rn(out, __fmul_rn(__fmul_rn(L.bary[pv0 + v], val[L.offset[pv0 + v]]), alpha));
+        norm_out[im.pix0 + pix] = (float)(1.0 / sqrt((double)out + 1e-20));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Mean-field iteration kernels.  Values / Q / unary rows are padded to Kp = 4*ceil(K/4) floats so
+// every access is one 16-byte vector per lane (pad channels carry zeros and are never read back as
+// labels).  Arithmetic per channel is exactly the scalar sequence of the oracle.
+//
+// splat: val[id] = sum over the lattice point's contributors (ascending pixel) of bary * (Q * norm)
+__global__ void crf_splat4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ Q,
+                                  const float* __restrict__ norm, float* __restrict__ val, int img0) {
+    const int b = img0 + blockIdx.y;
+    const PostDesc im = imgs[b];
+    const int K4 = im.Kp >> 2;
+    const int lo = L.idbase[b], hi = L.idbase[b + 1];
+    const f32x4* Q4 = reinterpret_cast<const f32x4*>(Q + im.qoff);
+    f32x4* V4 = reinterpret_cast<f32x4*>(val + im.voff[L.which]);
+    const int total = (hi - lo) * K4;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const int idl = t / K4, c = t - idl * K4;
+        const int e0 = L.seg_start[lo + idl], e1 = L.seg_start[lo + idl + 1];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int e = e0; e < e1; e += 4) {
+            // issue up to four independent gathers before the ordered accumulation
+            uint32_t pv[4];
+            f32x4 in[4];
+            float w[4], nr[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int ee = (e + j < e1) ? e + j : e1 - 1;
+                pv[j] = L.vals[ee];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t pixel = pv[j] / (uint32_t)L.D1;
+                in[j] = Q4[(size_t)(pixel - im.pix0) * K4 + c];
+                nr[j] = norm[pixel];
+                w[j] = L.bary[pv[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (e + j < e1) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[i] = __fadd_rn(acc[i], __fmul_rn(w[j], __fmul_rn(in[j][i], nr[j])));
+                }
+            }
         }
-        val[vbase + (size_t)idl * K + k] = acc;
+        V4[(size_t)idl * K4 + c] = acc;
     }
 }
 
 // one axis of the lattice blur: new = old + 0.5 * (n1 + n2), absent neighbours contribute 0
-__global__ void crf_blur_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ src,
-                                float* __restrict__ dst, int axis, int img0, int force_k1) {
+__global__ void crf_blur4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ src,
+                                 float* __restrict__ dst, int axis, int img0) {
     const int b = img0 + blockIdx.y;
     const PostDesc im = imgs[b];
-    const int K = force_k1 ? 1 : im.K;
+    const int K4 = im.Kp >> 2;
     const int lo = L.idbase[b], hi = L.idbase[b + 1];
-    const size_t vbase = force_k1 ? (size_t)lo : im.voff[L.which];
-    const int total = (hi - lo) * K;
+    const f32x4* S4 = reinterpret_cast<const f32x4*>(src + im.voff[L.which]);
+    f32x4* D4 = reinterpret_cast<f32x4*>(dst + im.voff[L.which]);
     const int* n1 = L.n1 + (size_t)axis * L.cap;
     const int* n2 = L.n2 + (size_t)axis * L.cap;
+    const int total = (hi - lo) * K4;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int idl = t / K, k = t - idl * K;
-        const int a = n1[lo + idl], c = n2[lo + idl];
-        const float va = a >= 0 ? src[vbase + (size_t)(a - lo) * K + k] : 0.f;
-        const float vc = c >= 0 ? src[vbase + (size_t)(c - lo) * K + k] : 0.f;
-        const float old = src[vbase + (size_t)idl * K + k];
-        dst[vbase + (size_t)idl * K + k] = (float)__dadd_rn((double)old, __dmul_rn(0.5, (double)__fadd_rn(va, vc)));
+        const int idl = t / K4, c = t - idl * K4;
+        const int a = n1[lo + idl], d = n2[lo + idl];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 va = a >= 0 ? S4[(size_t)(a - lo) * K4 + c] : zero;
+        const f32x4 vd = d >= 0 ? S4[(size_t)(d - lo) * K4 + c] : zero;
+        const f32x4 old = S4[(size_t)idl * K4 + c];
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = (float)__dadd_rn((double)old[i], __dmul_rn(0.5, (double)__fadd_rn(va[i], vd[i])));
+        D4[(size_t)idl * K4 + c] = o;
     }
 }
 
-// slice + symmetric normalisation + Potts compatibility, accumulated into the mean-field sum:
-//   f = norm * alpha-scaled slice ;  tmp = (first ? -U : tmp) - (-w * f)
-// mode 2: write norm[pixel] = 1 / sqrt(slice + 1e-20)  (lattice applied to the ones vector)
-__global__ void crf_slice_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ val,
-                                 const float* __restrict__ norm, const float* __restrict__ unary, float* __restrict__ tmp,
-                                 float* __restrict__ norm_out, float w, float alpha, int first, int img0, int mode) {
+// Fused tail of a mean-field iteration for a tile of 256 pixels:
+//   t = -U - (-w_g * norm_g * slice_g) - (-w_b * norm_b * slice_b)   (both lattices already blurred)
+//   Q = exp(t - max_k t) / sum_k          (per pixel, staged through LDS so global I/O stays 16-B wide)
+// pairwise == 0: Q = softmax(-U) (the initial marginals).
+constexpr int CRF_TP = 256;
+__global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, const CrfLattice Lb, const PostDesc* __restrict__ imgs,
+                                                         const float* __restrict__ vg, const float* __restrict__ vb,
+                                                         const float* __restrict__ norm_g, const float* __restrict__ norm_b,
+                                                         const float* __restrict__ unary, float* __restrict__ Q, float w_g,
+                                                         float w_b, float alpha_g, float alpha_b, int pairwise, int img0) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // [CRF_TP][Kp + 1]
     const int b = img0 + blockIdx.y;
     const PostDesc im = imgs[b];
-    const int K = mode == 2 ? 1 : im.K;
-    const int lo = L.idbase[b];
-    const size_t vbase = mode == 2 ? (size_t)lo : im.voff[L.which];
     const int n = im.H * im.W;
-    const int total = n * K;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int pix = t / K, k = t - pix * K;
-        const size_t pv0 = (size_t)(im.pix0 + pix) * L.D1;
-        float out = 0.f;
-        for (int v = 0; v < L.D1; v++) {
-            const int o = L.offset[pv0 + v];
-            const float wv = L.bary[pv0 + v];
-            out = __fadd_rn(out, __fmul_rn(__fmul_rn(wv, val[vbase + (size_t)(o - lo) * K + k]), alpha));
+    const int p0 = blockIdx.x * CRF_TP;
+    if (p0 >= n) return;
+    const int K = im.K, Kp = im.Kp, K4 = Kp >> 2, ldt = Kp + 1;
+    const int tid = threadIdx.x;
+    const f32x4* U4 = reinterpret_cast<const f32x4*>(unary + im.qoff);
+    f32x4* Q4 = reinterpret_cast<f32x4*>(Q + im.qoff);
+    const int lo_g = pairwise ? Lg.idbase[b] : 0, lo_b = pairwise ? Lb.idbase[b] : 0;
+    const f32x4* G4 = reinterpret_cast<const f32x4*>(vg + im.voff[0]);
+    const f32x4* B4 = reinterpret_cast<const f32x4*>(vb + im.voff[1]);
+    const int np = (n - p0) < CRF_TP ? (n - p0) : CRF_TP;
+    for (int item = tid; item < np * K4; item += 256) {
+        const int pl = item / K4, c = item - pl * K4;
+        const int pix = p0 + pl;
+        const f32x4 u = U4[(size_t)pix * K4 + c];
+        f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
+        if (pairwise) {
+            const size_t gp = (size_t)im.pix0 + pix;
+            {
+                f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                const size_t pv0 = gp * 3;
+#pragma unroll
+                for (int v = 0; v < 3; v++) {
+                    const f32x4 val = G4[(size_t)(Lg.offset[pv0 + v] - lo_g) * K4 + c];
+                    const float wv = Lg.bary[pv0 + v];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_g));
+                }
+                const float nr = norm_g[gp];
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_g, __fmul_rn(out[i], nr)));
+            }
+            {
+                f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                const size_t pv0 = gp * 6;
+#pragma unroll
+                for (int v = 0; v < 6; v++) {
+                    const f32x4 val = B4[(size_t)(Lb.offset[pv0 + v] - lo_b) * K4 + c];
+                    const float wv = Lb.bary[pv0 + v];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_b));
+                }
+                const float nr = norm_b[gp];
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_b, __fmul_rn(out[i], nr)));
+            }
         }
-        if (mode == 2) {
-            norm_out[im.pix0 + pix] = (float)(1.0 / sqrt((double)out + 1e-20));
-        } else {
-            const float f = __fmul_rn(-w, __fmul_rn(out, norm[im.pix0 + pix]));
-            const size_t qi = im.off + (size_t)pix * K + k;
-            const float base = first ? -unary[qi] : tmp[qi];
-            tmp[qi] = __fsub_rn(base, f);
-        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
     }
-}
-
-// Q = exp(x - max) / sum over the K labels of each pixel (x = -U when `neg`), NaN-propagating max
-__global__ void crf_softmax_kernel(const PostDesc* __restrict__ imgs, const float* __restrict__ x, float* __restrict__ Q,
-                                   int neg, int img0) {
-    const int b = img0 + blockIdx.y;
-    const PostDesc im = imgs[b];
-    const int n = im.H * im.W, K = im.K;
-    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < n; pix += gridDim.x * blockDim.x) {
-        const float* xi = x + im.off + (size_t)pix * K;
-        float* qi = Q + im.off + (size_t)pix * K;
-        float m = neg ? -xi[0] : xi[0];
+    __syncthreads();
+    if (tid < np) {
+        float* row = tile + tid * ldt;
+        float m = row[0];
         for (int k = 1; k < K; k++) {
-            const float v = neg ? -xi[k] : xi[k];
+            const float v = row[k];
             if (v > m || v != v) m = v;
         }
         float s = 0.f;
         for (int k = 0; k < K; k++) {
-            const float e = pnp_expf(__fsub_rn(neg ? -xi[k] : xi[k], m));
-            qi[k] = e;
+            const float e = pnp_expf(__fsub_rn(row[k], m));
+            row[k] = e;
             s = __fadd_rn(s, e);
         }
-        for (int k = 0; k < K; k++) qi[k] = __fdiv_rn(qi[k], s);
+        for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
+        for (int k = K; k < Kp; k++) row[k] = 0.f;
+    }
+    __syncthreads();
+    for (int item = tid; item < np * K4; item += 256) {
+        const int pl = item / K4, c = item - pl * K4;
+        const float* r = tile + pl * ldt + 4 * c;
+        Q4[(size_t)(p0 + pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
     }
 }
 
@@ -391,50 +490,55 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
 
 static float crf_alpha(int D) { return 1.0f / (1 + powf(2, (float)-D)); }
 
-// norm = 1 / sqrt(lattice(ones) + 1e-20) for images [0,B); va/vb: scratch of >= cap floats each.
-int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, float* va, float* vb, float* norm_out,
-                     hipStream_t s) {
+// norm = 1 / sqrt(lattice(ones) + 1e-20) for images [0,B); va/vb: scratch of >= (number of lattice points) floats.
+int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, float* va, float* vb,
+                     float* norm_out, hipStream_t s) {
     const int D = L.D1 - 1;
     const int nb = 1024;
-    hipLaunchKernelGGL(crf_splat_kernel, dim3(nb, B), dim3(256), 0, s, L, d_imgs, (const float*)nullptr,
-                       (const float*)nullptr, va, 0, 1);
+    hipLaunchKernelGGL(crf_splat1_kernel, dim3(nb, B), dim3(256), 0, s, L, d_imgs, va);
     float* src = va;
     float* dst = vb;
     for (int j = 0; j <= D; j++) {
-        hipLaunchKernelGGL(crf_blur_kernel, dim3(nb, B), dim3(256), 0, s, L, d_imgs, src, dst, j, 0, 1);
+        hipLaunchKernelGGL(crf_blur1_kernel, dim3(nb, B), dim3(256), 0, s, L, d_imgs, src, dst, j);
         float* t = src;
         src = dst;
         dst = t;
     }
-    hipLaunchKernelGGL(crf_slice_kernel, dim3(nb, B), dim3(256), 0, s, L, d_imgs, src, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, norm_out, 0.f, crf_alpha(D), 0, 0, 2);
+    const int nbp = (max_pixels + 255) / 256 < 512 ? (max_pixels + 255) / 256 : 512;
+    hipLaunchKernelGGL(crf_norm_kernel, dim3(nbp, B), dim3(256), 0, s, L, d_imgs, src, norm_out, crf_alpha(D));
     return ok();
 }
 
-// One pairwise term of one mean-field iteration for images [img0, img0+nimg):
-//   tmp = (first ? -U : tmp) - (-w) * norm * lattice(norm * Q)
-int crf_pairwise(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
-                 const float* unary, float* tmp, float* va, float* vb, float w, int first, hipStream_t s) {
+// lattice(norm * Q) for images [img0, img0+nimg): splat + (d+1) blurs.  Returns the buffer holding the result.
+int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
+               float* va, float* vb, const float** result, hipStream_t s) {
     const int D = L.D1 - 1;
-    const int nb = 2048;
-    hipLaunchKernelGGL(crf_splat_kernel, dim3(nb, nimg), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, 0);
+    const int nb = L.which == 0 ? 256 : 2048;
+    hipLaunchKernelGGL(crf_splat4_kernel, dim3(nb, nimg), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0);
     float* src = va;
     float* dst = vb;
     for (int j = 0; j <= D; j++) {
-        hipLaunchKernelGGL(crf_blur_kernel, dim3(nb, nimg), dim3(256), 0, s, L, d_imgs, src, dst, j, img0, 0);
+        hipLaunchKernelGGL(crf_blur4_kernel, dim3(nb, nimg), dim3(256), 0, s, L, d_imgs, src, dst, j, img0);
         float* t = src;
         src = dst;
         dst = t;
     }
-    hipLaunchKernelGGL(crf_slice_kernel, dim3(nb, nimg), dim3(256), 0, s, L, d_imgs, src, norm, unary, tmp,
-                       (float*)nullptr, w, crf_alpha(D), first, img0, 0);
+    *result = src;
     return ok();
 }
 
-int crf_softmax(const PostDesc* d_imgs, int img0, int nimg, const float* x, float* Q, int neg, int max_pixels,
-                hipStream_t s) {
-    const int nb = (max_pixels + 255) / 256 < 512 ? (max_pixels + 255) / 256 : 512;
-    hipLaunchKernelGGL(crf_softmax_kernel, dim3(nb, nimg), dim3(256), 0, s, d_imgs, x, Q, neg, img0);
+// Q <- softmax(-U - pairwise terms) (pairwise != 0) or softmax(-U) (pairwise == 0)
+int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
+               const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
+               float w_b, int pairwise, int max_pixels, int max_kp, hipStream_t s) {
+    const size_t smem = (size_t)CRF_TP * (max_kp + 1) * sizeof(float);
+    if (smem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(crf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return PNP_ERR_HIP;
+    }
+    hipLaunchKernelGGL(crf_update_kernel, dim3((max_pixels + CRF_TP - 1) / CRF_TP, nimg), dim3(256), smem, s, Lg, Lb, d_imgs,
+                       vg, vb, norm_g, norm_b, unary, Q, w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0);
     return ok();
 }
 

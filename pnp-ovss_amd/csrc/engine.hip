@@ -107,7 +107,10 @@ struct pnp_engine {
         double* d_wts = nullptr;
         int32_t* d_wt_off = nullptr;
         float *merged = nullptr, *thr = nullptr, *maps = nullptr, *maps2 = nullptr, *maps3 = nullptr, *stats = nullptr;
-        float *unary = nullptr, *Q = nullptr, *tmpq = nullptr, *va = nullptr, *vb = nullptr, *norm[2] = {nullptr, nullptr};
+        float *unary = nullptr, *Q = nullptr, *va = nullptr, *vb = nullptr, *vga = nullptr, *vgb = nullptr, *norm[2] = {nullptr, nullptr};
+        int Kpmax = 0, maxH = 0, maxW = 0, max_radius = 0, maxKp = 0;
+        size_t valg_cap = 0;
+        std::vector<int> gauss_sig;      // (H, W) list the Gaussian lattice was last built for
         const uint8_t* d_rgb = nullptr;
         const float* d_gt = nullptr;
         CrfLattice lat[2]{};
@@ -855,9 +858,10 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     KCHK(e, dalloc(e, &p.maps3, TP * K));
     KCHK(e, dalloc(e, &p.stats, B * K * 2));
     // CRF
-    KCHK(e, dalloc(e, &p.unary, TP * K));
-    KCHK(e, dalloc(e, &p.Q, TP * K));
-    KCHK(e, dalloc(e, &p.tmpq, TP * K));
+    const size_t Kp = (K + 3) / 4 * 4;
+    p.maxKp = (int)Kp;
+    KCHK(e, dalloc(e, &p.unary, TP * Kp));
+    KCHK(e, dalloc(e, &p.Q, TP * Kp));
     KCHK(e, dalloc(e, &p.norm[0], TP));
     KCHK(e, dalloc(e, &p.norm[1], TP));
     for (int t = 0; t < 2; t++) {
@@ -892,9 +896,12 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     p.sort_tmp = st;
     // lattice value buffers: the images of one chunk, bilateral upper bound (6 entries per pixel) x K
     const size_t chunk_pix = (size_t)std::min<int64_t>((int64_t)p.chunk * max_pixels_per_image, max_total_pixels);
-    p.val_cap = std::max(chunk_pix * 6 * K, cap6);
+    p.val_cap = std::max(chunk_pix * 6 * Kp, cap6);
     KCHK(e, dalloc(e, &p.va, p.val_cap));
     KCHK(e, dalloc(e, &p.vb, p.val_cap));
+    p.valg_cap = chunk_pix * 3 * Kp;
+    KCHK(e, dalloc(e, &p.vga, p.valg_cap));
+    KCHK(e, dalloc(e, &p.vgb, p.valg_cap));
     p.reserved = true;
     return PNP_OK;
 }
@@ -914,9 +921,9 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
     std::vector<size_t> label_off(B + 1, 0);
     std::vector<int32_t> wt_off(B + 1, 0);
     std::vector<double> wts;
-    size_t off = 0;
+    size_t off = 0, qoff = 0;
     int64_t pix = 0;
-    p.Cmax = p.Kmax = p.maxHW = 0;
+    p.Cmax = p.Kmax = p.maxHW = p.Kpmax = p.maxH = p.maxW = p.max_radius = 0;
     for (int i = 0; i < B; i++) {
         PostDesc& d = p.desc[i];
         d.H = b->H[i]; d.W = b->W[i]; d.C = b->n_classes[i]; d.has_bg = b->has_bg[i] ? 1 : 0; d.K = d.C + d.has_bg;
@@ -925,8 +932,14 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
         if (b->img_cls_off[i + 1] - b->img_cls_off[i] != d.C) return fail(e, PNP_ERR_ARG, "image %d: merge plan has %d classes, expected %d", i, b->img_cls_off[i + 1] - b->img_cls_off[i], d.C);
         d.pix0 = (int)pix;
         d.off = off;
+        d.Kp = (d.K + 3) / 4 * 4;
+        d.qoff = qoff;
         label_off[i] = (size_t)pix;
         off += (size_t)d.K * d.H * d.W;
+        qoff += (size_t)d.Kp * d.H * d.W;
+        p.Kpmax = std::max(p.Kpmax, d.Kp);
+        p.maxH = std::max(p.maxH, d.H);
+        p.maxW = std::max(p.maxW, d.W);
         pix += (int64_t)d.H * d.W;
         p.Cmax = std::max(p.Cmax, d.C);
         p.Kmax = std::max(p.Kmax, d.K);
@@ -940,6 +953,7 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
             phi[x + radius] = std::exp(-0.5 / (sigma * sigma) * (double)(x * x));
             sum += phi[x + radius];
         }
+        p.max_radius = std::max(p.max_radius, (b->blur_wts && b->blur_wt_off) ? b->blur_wt_off[i + 1] - b->blur_wt_off[i] - 1 : radius);
         wt_off[i] = (int32_t)wts.size();
         if (b->blur_wts && b->blur_wt_off) {
             for (int j = b->blur_wt_off[i]; j < b->blur_wt_off[i + 1]; j++) wts.push_back(b->blur_wts[j]);
@@ -960,9 +974,9 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
         for (int i = c0; i < std::min(B, c0 + p.chunk); i++)
             for (int t = 0; t < 2; t++) {
                 p.desc[i].voff[t] = v[t];
-                v[t] += (size_t)p.desc[i].H * p.desc[i].W * (t == 0 ? 3 : 6) * p.desc[i].K;
+                v[t] += (size_t)p.desc[i].H * p.desc[i].W * (t == 0 ? 3 : 6) * p.desc[i].Kp;
             }
-        if (v[1] > p.val_cap) return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", v[1], p.val_cap);
+        if (v[1] > p.val_cap || v[0] > p.valg_cap) return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", v[1], p.val_cap);
     }
     p.B = B;
     p.total_pix = pix;
@@ -982,7 +996,11 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
     p.has_crf = false;
     if (want_crf) {
         // PnP.py:1036-1041: POS_XY_STD = 3, Bi_XY_STD = 50, Bi_RGB_STD = 5 (features are fixed per batch)
+        std::vector<int> sig;
+        for (int i = 0; i < B; i++) { sig.push_back(p.desc[i].H); sig.push_back(p.desc[i].W); }
         for (int t = 0; t < 2; t++) {
+            // the Gaussian (xy-only) lattice depends on the image sizes alone: keep it across batches
+            if (t == 0 && sig == p.gauss_sig) continue;
             const int D1 = t == 0 ? 3 : 6;
             std::vector<int> sb(B), se(B);
             for (int i = 0; i < B; i++) {
@@ -995,12 +1013,13 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
             KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
                                       p.maxHW, p.seg_begin[t], p.seg_end[t], p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
                                       p.sort_tmp, p.sort_tmp_bytes, p.range_err, s));
-            KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.va, p.vb, p.norm[t], s));
+            KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.maxHW, p.va, p.vb, p.norm[t], s));
         }
         int err = 0;
         HIPCHK(e, hipMemcpyAsync(&err, p.range_err, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(e, hipStreamSynchronize(s));
         if (err) return fail(e, PNP_ERR_ARG, "lattice key out of packing range (image too large for the 64-bit key)");
+        p.gauss_sig = sig;
         p.has_crf = true;
     }
     p.prepared = true;
@@ -1036,7 +1055,7 @@ extern "C" int pnp_blur_minmax(pnp_engine* e, void* stream) {
     POST_READY(e);
     auto& p = e->post;
     hipStream_t s = (hipStream_t)stream;
-    KCHK(e, blur_maps(p.maps, p.maps3, p.maps2, p.d_desc, p.d_wts, p.d_wt_off, p.B, p.Kmax, p.maxHW, s));
+    KCHK(e, blur_maps(p.maps, p.maps3, p.maps2, p.d_desc, p.d_wts, p.d_wt_off, p.B, p.Kmax, p.maxH, p.maxW, p.max_radius, s));
     KCHK(e, minmax_normalize(p.maps2, p.d_desc, p.stats, p.B, p.Kmax, p.maxHW, 0, s));
     p.maps_in_2 = true;
     return PNP_OK;
@@ -1054,11 +1073,14 @@ extern "C" int pnp_densecrf(pnp_engine* e, int32_t iters, float pos_w, float pos
     KCHK(e, unary_from_maps(maps, p.d_desc, p.unary, p.B, p.maxHW, s));
     for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
         const int n = std::min(p.chunk, p.B - c0);
-        KCHK(e, crf_softmax(p.d_desc, c0, n, p.unary, p.Q, 1, p.maxHW, s));
+        KCHK(e, crf_update(p.lat[0], p.lat[1], p.d_desc, c0, n, p.vga, p.va, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 0,
+                           p.maxHW, p.Kpmax, s));
         for (int it = 0; it < iters; it++) {
-            KCHK(e, crf_pairwise(p.lat[0], p.d_desc, c0, n, p.Q, p.norm[0], p.unary, p.tmpq, p.va, p.vb, pos_w, 1, s));
-            KCHK(e, crf_pairwise(p.lat[1], p.d_desc, c0, n, p.Q, p.norm[1], p.unary, p.tmpq, p.va, p.vb, bi_w, 0, s));
-            KCHK(e, crf_softmax(p.d_desc, c0, n, p.tmpq, p.Q, 0, p.maxHW, s));
+            const float *rg = nullptr, *rb = nullptr;
+            KCHK(e, crf_filter(p.lat[0], p.d_desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, s));
+            KCHK(e, crf_filter(p.lat[1], p.d_desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, s));
+            KCHK(e, crf_update(p.lat[0], p.lat[1], p.d_desc, c0, n, rg, rb, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 1,
+                               p.maxHW, p.Kpmax, s));
         }
     }
     return PNP_OK;
@@ -1109,11 +1131,12 @@ extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, siz
     if (n == "dropped") return set(e->dropped, B * (size_t)e->PP);
     if (p.reserved) {
         const size_t mk = (size_t)p.max_total_pix * p.maxK * 4;
+        const size_t mq = (size_t)p.max_total_pix * p.maxKp * 4;
         if (n == "merged") return set(p.merged, (size_t)p.maxB * p.maxK * e->PP * 4);
         if (n == "maps") return set(p.maps_in_2 ? p.maps2 : p.maps, mk);
         if (n == "maps_pre_blur") return set(p.maps, mk);
-        if (n == "unary") return set(p.unary, mk);
-        if (n == "crf_q") return set(p.Q, mk);
+        if (n == "unary") return set(p.unary, mq);
+        if (n == "crf_q") return set(p.Q, mq);
         if (n == "crf_idbase_gauss") return set(p.lat[0].idbase, ((size_t)p.maxB + 1) * 4);
         if (n == "crf_idbase_bilateral") return set(p.lat[1].idbase, ((size_t)p.maxB + 1) * 4);
         if (n == "crf_norm_gauss") return set(p.norm[0], (size_t)p.max_total_pix * 4);

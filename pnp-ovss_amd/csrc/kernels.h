@@ -14,7 +14,9 @@ namespace pnp {
 // lattice value block (t = 0 Gaussian, 1 bilateral).
 struct PostDesc {
     int H, W, K, C, has_bg, pix0;
-    size_t off;
+    int Kp;            // K rounded up to a multiple of 4 (row stride of the CRF arrays)
+    size_t off;        // K*H*W blocks of the (K,H,W) map buffers
+    size_t qoff;       // Kp*H*W blocks of the pixel-major CRF arrays (unary, Q)
     size_t voff[2];
 };
 
@@ -70,7 +72,7 @@ int minmax_normalize(float* maps, const PostDesc* desc, float* stats, int B, int
                      hipStream_t s);
 int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipStream_t s);
 int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
-              int B, int Kmax, int maxHW, hipStream_t s);
+              int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s);
 int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, hipStream_t s);
 int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int lut_stride, uint8_t* labels,
                  const size_t* label_off, int pixel_major, int B, int maxHW, hipStream_t s);
@@ -83,11 +85,12 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
                       int B, size_t ent_total, int max_pixels, const int* d_seg_begin, const int* d_seg_end,
                       uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, void* temp,
                       size_t temp_bytes, int* d_range_err, hipStream_t s);
-int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, float* va, float* vb, float* norm_out,
-                     hipStream_t s);
-int crf_pairwise(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
-                 const float* unary, float* tmp, float* va, float* vb, float w, int first, hipStream_t s);
-int crf_softmax(const PostDesc* d_imgs, int img0, int nimg, const float* x, float* Q, int neg, int max_pixels,
-                hipStream_t s);
+int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, float* va, float* vb,
+                     float* norm_out, hipStream_t s);
+int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
+               float* va, float* vb, const float** result, hipStream_t s);
+int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
+               const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
+               float w_b, int pairwise, int max_pixels, int max_kp, hipStream_t s);
 
 }  // namespace pnp

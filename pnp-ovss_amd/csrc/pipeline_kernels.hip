@@ -276,36 +276,83 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return m >= n ? period - 1 - m : m;
 }
 
-__global__ void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out, const PostDesc* __restrict__ desc,
-                                 const double* __restrict__ wts, const int32_t* __restrict__ wt_off, int axis) {
+// Each thread owns up to 8 outputs of the tile and walks the taps once for all of them (8
+// independent fp64 chains hide the dadd latency at one wave per SIMD).  Output (r, c) of the tile
+// reads xs[r * row_stride + c + base + (+-j) * tap_stride].
+__device__ __forceinline__ void blur_tile_outputs(const double* __restrict__ xs, const double* __restrict__ wl, int radius,
+                                                  int row_stride, int base, int tap_stride, int TH, int TW, int y0, int x0,
+                                                  int H, int W, float* __restrict__ dst, int tid) {
+    constexpr int OPT = 8;
+    const int nout = TH * TW;
+    const double* ctr[OPT];
+    double acc[OPT];
+#pragma unroll
+    for (int i = 0; i < OPT; i++) {
+        int o = tid + 256 * i;
+        o = o < nout ? o : nout - 1;
+        const int r = o / TW, c = o - r * TW;
+        ctr[i] = xs + (size_t)r * row_stride + c + base;
+        acc[i] = __dmul_rn(ctr[i][0], wl[0]);
+    }
+    for (int j = radius; j >= 1; j--) {
+        const double wj = wl[j];
+        const int d = j * tap_stride;
+#pragma unroll
+        for (int i = 0; i < OPT; i++) acc[i] = __dadd_rn(acc[i], __dmul_rn(__dadd_rn(ctr[i][-d], ctr[i][d]), wj));
+    }
+#pragma unroll
+    for (int i = 0; i < OPT; i++) {
+        const int o = tid + 256 * i;
+        if (o >= nout) continue;
+        const int r = o / TW, c = o - r * TW;
+        if (y0 + r < H && x0 + c < W) dst[(size_t)(y0 + r) * W + x0 + c] = (float)acc[i];
+    }
+}
+
+// LDS-tiled: a workgroup stages its tile + halo once as fp64 (the conversion scipy's line buffer
+// does) and every tap is a conflict-free ds_read_b64; the per-output sum keeps scipy's order.
+// Tile = TH rows x TW cols of outputs; halo of `radius` along the filtered axis.
+__global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                        const PostDesc* __restrict__ desc, const double* __restrict__ wts,
+                                                        const int32_t* __restrict__ wt_off, int axis, int TH, int TW,
+                                                        int max_radius) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];
+    double* wl = tile;                               // [max_radius + 1] taps
+    double* xs = tile + (max_radius + 1);            // staged samples
     const int b = blockIdx.z, k = blockIdx.y;
     const PostDesc d = desc[b];
     if (k >= d.K) return;
-    const int H = d.H, W = d.W, n = H * W;
+    const int H = d.H, W = d.W;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const double* w = wts + wt_off[b];
     const int radius = wt_off[b + 1] - wt_off[b] - 1;
-    const float* src = in + d.off + (size_t)k * n;
-    float* dst = out + d.off + (size_t)k * n;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int y = i / W, x = i - y * W;
-        double tmp;
+    const float* src = in + d.off + (size_t)k * H * W;
+    float* dst = out + d.off + (size_t)k * H * W;
+    const int tid = threadIdx.x;
+    for (int j = tid; j <= radius; j += 256) wl[j] = w[j];
+    for (int tl = blockIdx.x; tl < tiles_x * tiles_y; tl += gridDim.x) {
+        const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();
         if (axis == 0) {
-            tmp = __dmul_rn((double)src[i], w[0]);
-            for (int j = radius; j >= 1; j--) {
-                const double a = (double)src[reflect_idx(y - j, H) * W + x];
-                const double c = (double)src[reflect_idx(y + j, H) * W + x];
-                tmp = __dadd_rn(tmp, __dmul_rn(__dadd_rn(a, c), w[j]));
+            const int rows = TH + 2 * radius;            // xs[rows][TW]
+            for (int i = tid; i < rows * TW; i += 256) {
+                const int r = i / TW, c = i - r * TW;
+                const int x = x0 + c < W ? x0 + c : W - 1;
+                xs[i] = (double)src[(size_t)reflect_idx(y0 - radius + r, H) * W + x];
             }
+            __syncthreads();
+            blur_tile_outputs(xs, wl, radius, TW, radius * TW, TW, TH, TW, y0, x0, H, W, dst, tid);
         } else {
-            tmp = __dmul_rn((double)src[i], w[0]);
-            const float* row = src + (size_t)y * W;
-            for (int j = radius; j >= 1; j--) {
-                const double a = (double)row[reflect_idx(x - j, W)];
-                const double c = (double)row[reflect_idx(x + j, W)];
-                tmp = __dadd_rn(tmp, __dmul_rn(__dadd_rn(a, c), w[j]));
+            const int cols = TW + 2 * radius;            // xs[TH][cols]
+            for (int i = tid; i < TH * cols; i += 256) {
+                const int r = i / cols, c = i - r * cols;
+                const int y = y0 + r < H ? y0 + r : H - 1;
+                xs[i] = (double)src[(size_t)y * W + reflect_idx(x0 - radius + c, W)];
             }
+            __syncthreads();
+            blur_tile_outputs(xs, wl, radius, cols, radius, 1, TH, TW, y0, x0, H, W, dst, tid);
         }
-        dst[i] = (float)tmp;
     }
 }
 
@@ -315,9 +362,9 @@ __global__ void blur_axis_kernel(const float* __restrict__ in, float* __restrict
 __global__ void unary_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc, float* __restrict__ unary) {
     const int b = blockIdx.y;
     const PostDesc d = desc[b];
-    const int n = d.H * d.W, K = d.K;
+    const int n = d.H * d.W, K = d.K, Kp = d.Kp;
     const float* m = maps + d.off;
-    float* u = unary + d.off;
+    float* u = unary + d.qoff;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float mx = m[i];
         for (int k = 1; k < K; k++) {
@@ -330,25 +377,26 @@ __global__ void unary_kernel(const float* __restrict__ maps, const PostDesc* __r
             float p = __fdiv_rn(pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)), s);
             if (p < 1e-5f) p = 1e-5f;
             else if (p > 1.0f) p = 1.0f;
-            u[(size_t)i * K + k] = -pnp_logf(p);
+            u[(size_t)i * Kp + k] = -pnp_logf(p);
         }
+        for (int k = K; k < Kp; k++) u[(size_t)i * Kp + k] = 0.f;
     }
 }
 
-// argmax over channels.  layout_pixel_major: Q[n][K] (CRF marginals) else maps[K][n].
+// argmax over channels.  pixel_major: Q[n][Kp] (CRF marginals, rows padded to Kp) else maps[K][n].
 // np.argmax semantics: first maximum, NaN counts as maximum.
 __global__ void argmax_kernel(const float* __restrict__ q, const PostDesc* __restrict__ desc, const int32_t* __restrict__ lut,
                               int lut_stride, uint8_t* __restrict__ labels, const size_t* __restrict__ label_off,
                               int pixel_major) {
     const int b = blockIdx.y;
     const PostDesc d = desc[b];
-    const int n = d.H * d.W, K = d.K;
-    const float* p = q + d.off;
+    const int n = d.H * d.W, K = d.K, Kp = d.Kp;
+    const float* p = q + (pixel_major ? d.qoff : d.off);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int best = 0;
-        float bv = pixel_major ? p[(size_t)i * K] : p[i];
+        float bv = pixel_major ? p[(size_t)i * Kp] : p[i];
         for (int k = 1; k < K; k++) {
-            const float v = pixel_major ? p[(size_t)i * K + k] : p[(size_t)k * n + i];
+            const float v = pixel_major ? p[(size_t)i * Kp + k] : p[(size_t)k * n + i];
             if (bv == bv && (v > bv || v != v)) { best = k; bv = v; }
         }
         labels[label_off[b] + i] = (uint8_t)lut[b * lut_stride + best];
@@ -424,10 +472,32 @@ int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipS
 }
 
 int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
-              int B, int Kmax, int maxHW, hipStream_t s) {
-    const int nb = (maxHW + 255) / 256 < 128 ? (maxHW + 255) / 256 : 128;
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(nb, Kmax, B), dim3(256), 0, s, in, tmp, desc, wts, wt_off, 0);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(nb, Kmax, B), dim3(256), 0, s, tmp, out, desc, wts, wt_off, 1);
+              int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s) {
+    // tile 32 x 64 outputs (2048 per workgroup); shrink the unfiltered extent when the halo is long
+    int TH = 32, TW = 64;
+    auto lds = [&](int th, int tw, int axis) {
+        return (size_t)(max_radius + 1 + (axis == 0 ? (th + 2 * max_radius) * tw : th * (tw + 2 * max_radius))) * sizeof(double);
+    };
+    int th0 = 32, tw0 = 64;                       // vertical pass: halo multiplies TW
+    while (lds(th0, tw0, 0) > 150 * 1024 && tw0 > 16) tw0 >>= 1;
+    int th1 = 32, tw1 = 64;                       // horizontal pass: halo multiplies TH
+    while (lds(th1, tw1, 1) > 150 * 1024 && th1 > 8) th1 >>= 1;
+    if (lds(th0, tw0, 0) > 160 * 1024 || lds(th1, tw1, 1) > 160 * 1024) return PNP_ERR_ARG;
+    (void)TH; (void)TW;
+    static size_t attr_bytes = 0;
+    const size_t need = lds(th0, tw0, 0) > lds(th1, tw1, 1) ? lds(th0, tw0, 0) : lds(th1, tw1, 1);
+    if (need > attr_bytes) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(blur_axis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(160 * 1024)) != hipSuccess)
+            return PNP_ERR_HIP;
+        attr_bytes = 160 * 1024;
+    }
+    const int t0 = ((maxW + tw0 - 1) / tw0) * ((maxH + th0 - 1) / th0);
+    const int t1 = ((maxW + tw1 - 1) / tw1) * ((maxH + th1 - 1) / th1);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(t0, Kmax, B), dim3(256), lds(th0, tw0, 0), s, in, tmp, desc, wts, wt_off, 0, th0, tw0,
+                       max_radius);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(t1, Kmax, B), dim3(256), lds(th1, tw1, 1), s, tmp, out, desc, wts, wt_off, 1, th1, tw1,
+                       max_radius);
     return ok();
 }
 

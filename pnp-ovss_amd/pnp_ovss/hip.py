@@ -336,10 +336,11 @@ class Engine:
         return out
 
     def post_q(self):
-        """Per-image CRF marginals, pixel-major (H*W, K)."""
+        """Per-image CRF marginals, pixel-major (H*W, K) (rows are padded to a multiple of 4 on device)."""
         flat = self.buffer("crf_q")
         out, o = [], 0
         for (h, w), k in zip(self._post_sizes, self._post_K):
-            out.append(flat[o:o + k * h * w].view(h * w, k))
-            o += k * h * w
+            kp = (k + 3) // 4 * 4
+            out.append(flat[o:o + kp * h * w].view(h * w, kp)[:, :k])
+            o += kp * h * w
         return out

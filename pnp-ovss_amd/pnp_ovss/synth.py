@@ -110,13 +110,15 @@ CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)   # 
 CLIP_STD = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
 
 
-def synth_images(batch: int, size: int, seed: int = 1234, block: int = 8):
-    """Seeded block-smoothed uint8 RGB noise: returns
+def synth_images(batch: int, size: int, seed: int = 1234, block: int = 8, noise: int = 12):
+    """Seeded block-smoothed uint8 RGB noise: 8x8 blocks of uniform colour plus
+    +-`noise` levels of per-pixel noise (sensor-noise stand-in; it sets how many bilateral lattice
+    points an image occupies: ~3.6 / pixel at 12, ~0.9 / pixel at 4).  Returns
     (rgb uint8 (B,H,W,3) used by the CRF bilateral term, normalised fp32 (B,3,H,W) network input)."""
     g = np.random.default_rng([seed, 7])
     nb = (size + block - 1) // block
     coarse = g.integers(0, 256, size=(batch, nb, nb, 3), dtype=np.int64)
-    fine = g.integers(-12, 13, size=(batch, size, size, 3), dtype=np.int64)
+    fine = g.integers(-noise, noise + 1, size=(batch, size, size, 3), dtype=np.int64)
     rgb = np.repeat(np.repeat(coarse, block, axis=1), block, axis=2)[:, :size, :size]
     rgb = np.clip(rgb + fine, 0, 255).astype(np.uint8)
     x = rgb.astype(np.float32) / np.float32(255.0)
