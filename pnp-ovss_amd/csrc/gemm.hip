@@ -16,6 +16,270 @@
 
 namespace pnp {
 
+// ---- tile rasterisation.  Blocks b and b+8 share an XCD (round-robin dispatch), so each XCD gets
+// a contiguous run of tile ids; inside the run tiles are walked in groups of GM row-tiles x all
+// column tiles, column-major inside the group, so the ~32 workgroups resident on one XCD cover a
+// GM x (32/GM) patch: they share GM A-panels and 32/GM B-panels out of the 4 MB L2 instead of
+// streaming 32 different A-panels from Infinity Cache / HBM.
+template <int GM>
+__device__ __forceinline__ void tile_coords(int bid, int nbm, int nbn, int& bm, int& bn) {
+    const int nwg = nbm * nbn;
+    const int qd = nwg >> 3, rm = nwg & 7, x = bid & 7, i = bid >> 3;
+    const int id = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + i;
+    const int per_group = GM * nbn;
+    const int rg = id / per_group, rem = id - rg * per_group;
+    const int rows = (nbm - rg * GM) < GM ? (nbm - rg * GM) : GM;
+    bn = rem / rows;
+    bm = rg * GM + (rem - bn * rows);
+}
+
+// ---- shared epilogue: one fragment = row m, 4 consecutive columns n..n+3
+struct RowCtx {
+    int orow;
+    const float* resid_row;
+    float bias_row;
+};
+
+__device__ __forceinline__ RowCtx row_ctx(const GemmArgs& g, int m) {
+    RowCtx rc;
+    rc.orow = m;
+    rc.resid_row = nullptr;
+    if (g.row_div > 0) {                         // patch-embed rows -> token rows (skip cls)
+        const int b = m / g.row_div, p = m - b * g.row_div;
+        rc.orow = b * (g.row_div + 1) + 1 + p;
+        if (g.resid) rc.resid_row = g.resid + (size_t)(1 + p) * g.ldr;   // pos_embed[1+p]
+    } else if (g.resid) {
+        rc.resid_row = g.resid + (size_t)m * g.ldr;
+    }
+    rc.bias_row = (g.bias && g.bias_on_rows) ? g.bias[m] : 0.f;
+    return rc;
+}
+
+template <typename T>
+__device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, f32x4 v, int m, int n) {
+    const int orow = rc.orow;
+    if (g.bias) {
+        if (g.bias_on_rows) {
+            v += rc.bias_row;
+        } else {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+            v += bv;
+        }
+    }
+    if (g.mode == GEMM_EPI_GELU) {
+        if (g.aux) *reinterpret_cast<f32x4*>(g.aux + (size_t)orow * g.ld_aux + n) = v;
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+    } else if (g.mode == GEMM_EPI_GELU_GRAD) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(g.aux + (size_t)orow * g.ld_aux + n);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] *= gelu_erf_grad(u[e]);
+    }
+    if (rc.resid_row) {
+        const f32x4 rv = *reinterpret_cast<const f32x4*>(rc.resid_row + n);
+        v += rv;
+    }
+    // column remap (token index -> per-image padded index) for transposed outputs
+    size_t ocol = n;
+    bool contiguous = true;
+    if (g.col_div > 0) {
+        const int b = n / g.col_div, t = n - b * g.col_div;
+        ocol = (size_t)b * g.col_pad + t;
+        contiguous = (t + 3 < g.col_div) && (n + 3 < g.Nvalid);
+    } else {
+        contiguous = (n + 3 < g.Nvalid);
+    }
+    if (contiguous) {
+        if (g.out_f32) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)orow * g.ldo + ocol) = v;
+        if (g.out_t) {
+            T* o = reinterpret_cast<T*>(g.out_t) + (size_t)orow * g.ldo_t + ocol;
+            if constexpr (sizeof(T) == 2) {
+                bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                *reinterpret_cast<bf16x4*>(o) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(o) = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int ne = n + e;
+            if (ne >= g.Nvalid) break;
+            size_t oc = ne;
+            if (g.col_div > 0) {
+                const int b = ne / g.col_div, t = ne - b * g.col_div;
+                oc = (size_t)b * g.col_pad + t;
+            }
+            if (g.out_f32) g.out_f32[(size_t)orow * g.ldo + oc] = v[e];
+            if (g.out_t) reinterpret_cast<T*>(g.out_t)[(size_t)orow * g.ldo_t + oc] = from_f32<T>(v[e]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Large-problem kernel: 256 x 128 block tile, 8 waves (4 x 2, 64 x 64 each), 128-byte k-slab,
+// operands streamed global -> LDS by `global_load_lds_dwordx4` (no VGPR staging) into a 3-deep
+// ring so two k-slabs are always in flight; one raw s_barrier per k-slab with a COUNTED vmcnt
+// (never 0 in the main loop).  The LDS image is lane-linear per DMA (8 rows x 128 B), so the XOR
+// swizzle is applied to the per-lane SOURCE address and again on the fragment read.
+constexpr int BIG_BM = 256, BIG_BN = 128, BIG_NS = 3;
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(const GemmArgs g) {
+    constexpr int ROWB = 128;
+    constexpr int BK = ROWB / Elem<T>::kBytes;
+    constexpr int BM = BIG_BM, BN = BIG_BN, NS = BIG_NS;
+    constexpr int STAGE = (BM + BN) * ROWB;          // 48 KB
+    constexpr int TM = 4, TN = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
+    int bm, bn;
+    tile_coords<4>(blockIdx.x, nbm, nbn, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    // DMA assignment: wave w moves A rows [32w, 32w+32) (4 DMAs of 8 rows) and B rows [16w, 16w+16) (2 DMAs)
+    const char* src[6];
+    int dst[6];
+    {
+        const char* Ab = reinterpret_cast<const char*>(g.A);
+        const char* Bb = reinterpret_cast<const char*>(g.B);
+        const size_t lda_b = (size_t)g.lda * Elem<T>::kBytes, ldb_b = (size_t)g.ldb * Elem<T>::kBytes;
+        const int pc = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int row = wave * 32 + i * 8 + (lane >> 3);
+            int gr = m0 + row;
+            gr = gr < g.M ? gr : g.M - 1;
+            src[i] = Ab + (size_t)gr * lda_b + swz_chunk<ROWB>(row, pc) * 16;
+            dst[i] = (wave * 32 + i * 8) * ROWB;                       // wave-uniform DMA base
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int row = wave * 16 + i * 8 + (lane >> 3);
+            int gr = n0 + row;
+            gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
+            src[4 + i] = Bb + (size_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
+            dst[4 + i] = BM * ROWB + (wave * 16 + i * 8) * ROWB;
+        }
+    }
+    auto issue = [&](int kt) {
+        char* stage = smem + (kt % NS) * STAGE;
+        const size_t koff = (size_t)kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
+                                             (__attribute__((address_space(3))) void*)(stage + dst[i]), 16, 0, 0);
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int j = 0; j < TM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    constexpr int KSTEPS = BK / 32;
+    auto read_frags = [&](Frag<T>* fa, Frag<T>* fb, int kt, int ks) {
+        const char* cA = smem + (kt % NS) * STAGE;
+        const char* cB = cA + BM * ROWB;
+#pragma unroll
+        for (int j = 0; j < TM; j++) lds_frag<ROWB>(fa[j], cA, wm * 64 + j * 16 + r, ks, q);
+#pragma unroll
+        for (int i = 0; i < TN; i++) lds_frag<ROWB>(fb[i], cB, wn * 64 + i * 16 + r, ks, q);
+    };
+    auto mma_step = [&](const Frag<T>* fa, const Frag<T>* fb) {
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int j = 0; j < TM; j++) mma16(acc[i][j], fb[i], fa[j]);
+    };
+    if constexpr (KSTEPS == 2) {
+        // Pipeline (bf16): every MFMA cluster overlaps the fragment reads of the NEXT k-step, and the
+        // slab hand-over (counted vmcnt + one s_barrier + next DMA issue) sits between two clusters
+        // whose operands are already in registers.  Slabs kt+1 (landed), kt+2 (in flight) and kt+3
+        // (just issued into slab kt's slot, whose data is fully in registers) share the 3-slot ring.
+        issue(0);
+        if (nk > 1) issue(1);
+        if (nk > 2) issue(2);
+        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        Frag<T> fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        read_frags(fa0, fb0, 0, 0);
+        for (int kt = 0; kt < nk; kt++) {
+            read_frags(fa1, fb1, kt, 1);
+            mma_step(fa0, fb0);
+#pragma unroll
+            for (int x = 0; x < 8; x++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            }
+            if (kt + 1 < nk) {
+                // own reads of slab kt are complete, slab kt+1 has landed (kt+2 may stay in flight)
+                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 3 < nk) issue(kt + 3);
+                read_frags(fa0, fb0, kt + 1, 0);
+                mma_step(fa1, fb1);
+#pragma unroll
+                for (int x = 0; x < 8; x++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            } else {
+                mma_step(fa1, fb1);
+            }
+        }
+    } else {
+        issue(0);
+        if (nk > 1) issue(1);
+        for (int kt = 0; kt < nk; kt++) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) issue(kt + 2);
+            Frag<T> fa[TM], fb[TN];
+            read_frags(fa, fb, kt, 0);
+            mma_step(fa, fb);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TM; j++) {
+        const int m = m0 + wm * 64 + j * 16 + r;
+        if (m >= g.M) continue;
+        const RowCtx rc = row_ctx(g, m);
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+            const int n = n0 + wn * 64 + i * 16 + q * 4;
+            if (n >= g.Nvalid) continue;
+            store_frag<T>(g, rc, acc[i][j], m, n);
+        }
+    }
+}
+
+template <typename T>
+static int launch_big(const GemmArgs& g, hipStream_t s) {
+    const int nbm = (g.M + BIG_BM - 1) / BIG_BM, nbn = g.N / BIG_BN;
+    const size_t smem = (size_t)BIG_NS * (BIG_BM + BIG_BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return PNP_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_big_kernel<T>), dim3(nbm * nbn), dim3(512), smem, s, g);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     constexpr int ROWB = 128;                       // bytes of k per LDS row per stage
@@ -32,16 +296,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     const int r = lane & 15, q = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD/L2 (round-robin dispatch), so give each
-    // XCD a contiguous run of tiles that walk M fastest (they re-use one B panel out of L2).
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
-    const int nwg = nbm * nbn;
-    int bid = blockIdx.x;
-    {
-        const int qd = nwg >> 3, rm = nwg & 7, x = bid & 7, i = bid >> 3;
-        bid = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + i;
-    }
-    const int bm = bid % nbm, bn = bid / nbm;
+    int bm, bn;
+    tile_coords<8>(blockIdx.x, nbm, nbn, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
 
     const char* Ab = reinterpret_cast<const char*>(g.A);
@@ -128,77 +385,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     for (int j = 0; j < TM; j++) {
         const int m = m0 + wm * WTM + j * 16 + r;
         if (m >= g.M) continue;
-        int orow = m;
-        const float* resid_row = nullptr;
-        if (g.row_div > 0) {                         // patch-embed rows -> token rows (skip cls)
-            const int b = m / g.row_div, p = m - b * g.row_div;
-            orow = b * (g.row_div + 1) + 1 + p;
-            if (g.resid) resid_row = g.resid + (size_t)(1 + p) * g.ldr;   // pos_embed[1+p]
-        } else if (g.resid) {
-            resid_row = g.resid + (size_t)m * g.ldr;
-        }
-        const float bias_row = (g.bias && g.bias_on_rows) ? g.bias[m] : 0.f;
+        const RowCtx rc = row_ctx(g, m);
 #pragma unroll
         for (int i = 0; i < TN; i++) {
             const int n = n0 + wn * WTN + i * 16 + q * 4;
             if (n >= g.Nvalid) continue;
-            f32x4 v = acc[i][j];
-            if (g.bias) {
-                if (g.bias_on_rows) {
-                    v += bias_row;
-                } else {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-                    v += bv;
-                }
-            }
-            if (g.mode == GEMM_EPI_GELU) {
-                if (g.aux) *reinterpret_cast<f32x4*>(g.aux + (size_t)orow * g.ld_aux + n) = v;
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
-            } else if (g.mode == GEMM_EPI_GELU_GRAD) {
-                const f32x4 u = *reinterpret_cast<const f32x4*>(g.aux + (size_t)orow * g.ld_aux + n);
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] *= gelu_erf_grad(u[e]);
-            }
-            if (resid_row) {
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(resid_row + n);
-                v += rv;
-            }
-            // column remap (token index -> per-image padded index) for transposed outputs
-            size_t ocol = n;
-            bool contiguous = true;
-            if (g.col_div > 0) {
-                const int b = n / g.col_div, t = n - b * g.col_div;
-                ocol = (size_t)b * g.col_pad + t;
-                contiguous = (t + 3 < g.col_div) && (n + 3 < g.Nvalid);
-            } else {
-                contiguous = (n + 3 < g.Nvalid);
-            }
-            if (contiguous) {
-                if (g.out_f32) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)orow * g.ldo + ocol) = v;
-                if (g.out_t) {
-                    T* o = reinterpret_cast<T*>(g.out_t) + (size_t)orow * g.ldo_t + ocol;
-                    if constexpr (sizeof(T) == 2) {
-                        bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                        *reinterpret_cast<bf16x4*>(o) = pk;
-                    } else {
-                        *reinterpret_cast<f32x4*>(o) = v;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int ne = n + e;
-                    if (ne >= g.Nvalid) break;
-                    size_t oc = ne;
-                    if (g.col_div > 0) {
-                        const int b = ne / g.col_div, t = ne - b * g.col_div;
-                        oc = (size_t)b * g.col_pad + t;
-                    }
-                    if (g.out_f32) g.out_f32[(size_t)orow * g.ldo + oc] = v[e];
-                    if (g.out_t) reinterpret_cast<T*>(g.out_t)[(size_t)orow * g.ldo_t + oc] = from_f32<T>(v[e]);
-                }
-            }
+            store_frag<T>(g, rc, acc[i][j], m, n);
         }
     }
 }
@@ -244,7 +436,7 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     }
     const double fl = 2.0 * g.M * (double)g.N * g.K;
     g.N = (g.N + 127) / 128 * 128;
-    const int r = dtype_bf16 ? launch_cfg<bf16, 128, 128>(g, s) : launch_cfg<float, 128, 128>(g, s);
+    const int r = dtype_bf16 ? launch_big<bf16>(g, s) : launch_big<float>(g, s);
     if (timed) {
         (void)hipEventRecord(pf.ev1[pf.used], s);
         pf.used++;
