@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's `PnP_OVSS_0514_updated_segmentation.py` command line on MI355X.
+
+Same flags (reference get_args_parser, :57-106), same one-process-per-GPU layout (:1439 mp.spawn ->
+here torchrun or the built-in spawn), same outputs: per-batch confusion matrices saved as
+`{save_path}/hist_withfiltered_caption/img_{id}_max_blocknum_{L}_atthead_{h}.npy` and
+`{save_path}/all_drop_hist_with_filtered_caption/...` (:505-520) so the reference's own
+Calculate_mIoU.py reads them.  New: `--data_type synthetic` (no dataset on disk), `--dtype`,
+`--checkpoint`, `--vocab`; the final histogram is additionally all-reduced over RCCL and printed.
+
+Device work happens in libpnp_hip.so via pnp_ovss.model.Segmenter; this file is host orchestration.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from pnp_ovss import host, synth  # noqa: E402
+from pnp_ovss.datasets import make_dataset  # noqa: E402
+from pnp_ovss.model import Segmenter  # noqa: E402
+
+
+def get_args_parser():
+    p = argparse.ArgumentParser("image caption localization with ITM", add_help=True)
+    p.add_argument("--batch_size", default=2, type=int)
+    p.add_argument("--num_workers", default=0, type=int)
+    p.add_argument("--gen_multiplecap_withpnpvqa", default="label")
+    p.add_argument("--save_path", default="Eval_test_ddp")
+    p.add_argument("--home_dir", default="/home/letitiabanana/LAVIS/")
+    p.add_argument("--master_port", default="12355")
+    p.add_argument("--existing_att_path", default=None)
+    p.add_argument("--cam_out_dir", default=None, type=str)
+    p.add_argument("--del_patch_num", default=None)
+    p.add_argument("--max_att_block_num", default=10, type=int)
+    p.add_argument("--img_size", default=768, type=int)
+    p.add_argument("--world_size", default=4, type=int)
+    p.add_argument("--ensemble_blocks", default=None, type=str)
+    p.add_argument("--drop_iter", default=10, type=int)
+    p.add_argument("--prune_att_head", default=None)
+    p.add_argument("--sort_threshold", default=None, type=float)
+    p.add_argument("--edge_map_for_clip", action="store_true")
+    p.add_argument("--final_att_threshold", default=0.05)
+    p.add_argument("--search", default=None)
+    p.add_argument("--layer", default=None, type=str)
+    p.add_argument("--cal_token_sim_forall_layerhead", action="store_true")
+    p.add_argument("--in_the_wild", action="store_true")
+    p.add_argument("--data_type", default=None, type=str, help="voc, psc, ade20k or synthetic")
+    p.add_argument("--postprocess", default=None, type=str, help="blur or crf or blur+crf")
+    p.add_argument("--threshold", default=None, type=float)
+    # additions
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--checkpoint", default=None, help="BLIP ITM-large checkpoint (.pth); default: seeded synthetic weights")
+    p.add_argument("--vocab", default=None, help="bert-base-uncased vocab.txt")
+    p.add_argument("--synthetic_images", default=70, type=int)
+    p.add_argument("--max_batches", default=0, type=int)
+    return p
+
+
+def ddp_setup(args, rank, world_size):
+    """reference :45-54 (NCCL on localhost) -> RCCL via torch.distributed; gloo when no GPU."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(args.master_port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+
+
+def main(rank, world_size, args):
+    tic = time.perf_counter()
+    if world_size > 1:
+        ddp_setup(args, rank, world_size)
+    torch.cuda.set_device(rank)
+    if args.prune_att_head is None:
+        raise SystemExit("--prune_att_head is required (reference :277)")
+    if args.del_patch_num is None or "sort_thresh" not in args.del_patch_num:
+        raise SystemExit('--del_patch_num must contain "sort_thresh" (reference :645-647)')
+    ds = make_dataset(args, rank, world_size)
+    from lavis.models import load_model_and_preprocess
+    model, vis_processors, text_processors = load_model_and_preprocess(
+        "blip_image_text_matching", "large", device=rank, is_eval=True, img_size=args.img_size,
+        max_batch=args.batch_size, stash_layer=args.max_att_block_num - 1, bf16=(args.dtype == "bf16"),
+        checkpoint=args.checkpoint, vocab=args.vocab, max_text_len=ds.max_text_len)
+    n_class = len(ds.cats) + 1
+    seg = Segmenter(model, args.data_type if args.data_type != "synthetic" else "voc", n_class, threshold=args.threshold,
+                    postprocess=args.postprocess, max_pixels_per_image=ds.max_pixels, max_channels=ds.max_channels)
+    layer, head = args.max_att_block_num, int(args.prune_att_head)
+    for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
+        Path(f"{args.save_path}/{d}/").mkdir(parents=True, exist_ok=True)
+    n_img = 0
+    t_loop = time.perf_counter()
+    for bi, batch in enumerate(ds.batches(args.batch_size)):
+        if args.max_batches and bi >= args.max_batches:
+            break
+        best, caps = [], []
+        for img_id in batch["img_ids"]:
+            b, names, cap = ds.predicted_classes(img_id)
+            best.append(b)
+            caps.append(cap)
+        seg.hist_1drop.zero_()
+        seg.hist_ndrop.zero_()
+        l1, ln = seg.run(args, batch["imgs"], caps, best, batch["org_images"], batch["label_trues"], run_1drop=True)
+        torch.cuda.synchronize()
+        h1 = seg.hist_1drop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
+        hn = seg.hist_ndrop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
+        first = batch["img_ids"][0]
+        np.save(f"{args.save_path}/hist_withfiltered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", h1)
+        if ln is not None:
+            np.save(f"{args.save_path}/all_drop_hist_with_filtered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", hn)
+        print(batch["img_ids"][:3], "miou filtered_caption", host.scores_from_hist(h1)["Mean IoU"],
+              "miou all_drop", host.scores_from_hist(hn)["Mean IoU"] if ln is not None else None, flush=True)
+        n_img += len(batch["img_ids"])
+        ds.total_hist += hn if ln is not None else h1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t_loop
+    total = torch.from_numpy(ds.total_hist).to(torch.device("cuda", rank))
+    if world_size > 1:
+        dist.all_reduce(total)                  # RCCL reduce of the confusion matrix (the reference sums files offline)
+    if rank == 0:
+        s = host.scores_from_hist(total.cpu().numpy())
+        print(json.dumps({"images": n_img * world_size, "images_per_sec_rank0": n_img / dt, "Mean IoU": float(s["Mean IoU"]),
+                          "Pixel Accuracy": float(s["Pixel Accuracy"]), "FWIoU": float(s["Frequency Weighted IoU"])}))
+        print(f"Time: total running time for {n_img} images/rank {time.perf_counter() - tic:0.4f} seconds")
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    args = get_args_parser().parse_args()
+    if "RANK" in os.environ:                    # launched by torchrun: one rank per GPU
+        main(int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), args)
+    elif args.world_size > 1:
+        import torch.multiprocessing as mp
+        mp.spawn(main, args=(args.world_size, args), nprocs=args.world_size)
+    else:
+        main(0, 1, args)

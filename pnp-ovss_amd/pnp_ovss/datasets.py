@@ -1,0 +1,116 @@
+"""Input side of the hot path (host, row a-15 of SURVEY.md §8): the tensors the reference's datasets
+deliver to the driver (`img0`, `img_id`, original RGB for the CRF, ground-truth label map), sharded
+across ranks like `DataLoader(..., sampler=DistributedSampler(dataset))` (Load_datasets.py:15-26).
+
+  synthetic  seeded images + one-word-piece-per-class captions (no files needed; bench / CI)
+  voc        Dataset.py:349-445 (bicubic resize to img_size, CLIP mean/std), PnP.py:901-955 (GT / RGB)
+  psc        Dataset.py:889-991 (same transform), Pascal-Context 59 classes (Load_datasets.py:30-44)
+ADE20K / COCO loaders are the next row; they need files that are not in this image.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import host, synth
+
+PSC_NAMES = ("aeroplane bag bed bedclothes bench bicycle bird boat book bottle building bus cabinet car cat ceiling "
+             "chair cloth computer cow cup curtain dog door fence floor flower food grass ground horse keyboard light "
+             "motorbike mountain mouse person plate platform pottedplant road rock sheep shelves sidewalk sign sky snow "
+             "sofa table track train tree truck tvmonitor wall water window wood").split()
+
+
+class _Base:
+    max_text_len = 64
+    max_channels = 24
+
+    def __init__(self, args, rank, world_size, cats):
+        self.args, self.rank, self.world = args, rank, world_size
+        self.cats = cats
+        self.nms = list(cats.values())
+        n = len(cats) + 1
+        self.total_hist = np.zeros((n, n), dtype=np.float64)
+
+    def _indices(self, n):
+        return host.shard_indices(n, self.rank, self.world, seed=0, shuffle=True)
+
+    def batches(self, batch_size):
+        idx = self._indices(len(self))
+        for o in range(0, len(idx), batch_size):
+            items = [self[i] for i in idx[o:o + batch_size]]
+            yield {"imgs": torch.stack([it[0] for it in items]), "img_ids": [it[1] for it in items],
+                   "org_images": [it[2] for it in items], "label_trues": [it[3] for it in items]}
+
+
+class SyntheticDataset(_Base):
+    """`--data_type synthetic`: 336^2-style seeded images, all-VOC-class captions."""
+
+    def __init__(self, args, rank, world_size):
+        super().__init__(args, rank, world_size, dict(host.VOC_CATS))
+        self.n = int(args.synthetic_images)
+        self.max_pixels = args.img_size * args.img_size
+        self.names = [f"c{i}" for i in range(20)]          # short names: one word piece each with SynthTokenizer
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        S = self.args.img_size
+        rgb, img = synth.synth_images(1, S, seed=10_000 + i, noise=4)
+        gt = np.random.default_rng(i).integers(0, 21, size=(S, S)).astype(np.float32)
+        return torch.from_numpy(img[0]), f"{2007 + i % 6}_{i:06d}", rgb[0], gt
+
+    def predicted_classes(self, img_id):
+        k = 1 + int(img_id.split("_")[1]) % 20
+        best = list(range(k))
+        return best, [self.names[b] for b in best], "A picture of " + " ".join(self.names[b] for b in best)
+
+
+class VocLikeDataset(_Base):
+    def __init__(self, args, rank, world_size, kind):
+        from PIL import Image                                    # noqa: F401  (fail early if missing)
+        cats = dict(host.VOC_CATS) if kind == "voc" else {i + 1: n for i, n in enumerate(PSC_NAMES)}
+        super().__init__(args, rank, world_size, cats)
+        self.kind = kind
+        home = args.home_dir
+        if kind == "voc":
+            self.img_dir = f"{home}/VOCdevkit/VOC2012/JPEGImages"
+            self.gt_dir = f"{home}/VOCdevkit/VOC2012/SegmentationClass"
+            split = f"{home}/VOCdevkit/VOC2012/ImageSets/Segmentation/val.txt"
+        else:
+            self.img_dir = f"{home}/VOCdevkit/VOC2012/JPEGImages"
+            self.gt_dir = f"{home}/mmsegmentation/data/VOCdevkit/VOC2010/SegmentationClassContext"
+            split = f"{home}/mmsegmentation/data/VOCdevkit/VOC2010/ImageSets/SegmentationContext/val.txt"
+        with open(split) as f:
+            self.ids = [l.strip() for l in f if l.strip()]
+        self.gpt = host.GptClassTable(f"{home}/GPT4o_classification/{kind}_classification_noboundary.json", kind)
+        self.max_pixels = 512 * 512
+        self.mean = np.array(synth.CLIP_MEAN, dtype=np.float32).reshape(3, 1, 1)
+        self.std = np.array(synth.CLIP_STD, dtype=np.float32).reshape(3, 1, 1)
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        img_id = self.ids[i]
+        img = Image.open(os.path.join(self.img_dir, img_id + ".jpg")).convert("RGB")
+        org = np.asarray(img)
+        S = self.args.img_size
+        x = np.asarray(img.resize((S, S), Image.BICUBIC), dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
+        x = (x - self.mean) / self.std
+        gt = np.float32(Image.open(os.path.join(self.gt_dir, img_id + ".png")))
+        if self.kind == "voc":
+            gt[gt == 255] = 0                                    # PnP.py:908
+        return torch.from_numpy(np.ascontiguousarray(x)), img_id, org, gt
+
+    def predicted_classes(self, img_id):
+        return self.gpt.lookup(img_id, self.nms)
+
+
+def make_dataset(args, rank, world_size):
+    if args.data_type == "synthetic":
+        return SyntheticDataset(args, rank, world_size)
+    if args.data_type in ("voc", "psc"):
+        return VocLikeDataset(args, rank, world_size, args.data_type)
+    raise SystemExit(f"--data_type {args.data_type!r}: supported here: synthetic, voc, psc (ade20k / coco loaders are next)")

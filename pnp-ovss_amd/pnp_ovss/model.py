@@ -1,0 +1,252 @@
+"""Python host mirror of the reference's model interface for the hot path, backed by the HIP engine.
+
+Reference surface kept:
+  * `load_model_and_preprocess("blip_image_text_matching", "large", device=..., is_eval=True)`
+    -> (model, vis_processors, txt_processors)                     (PnP.py:1212-1213; lavis shim)
+  * `model.tokenizer(...)`, `model.tokenizer.decode([id])`          (PnP.py:271,317,608,813)
+  * `model.text_encoder.base_model.base_model.encoder.layer[i].crossattention.self.save_attention`
+    + get_attention_map / get_attn_gradients                       (PnP.py:294-298; med.py:162-180)
+  * `compute_gradcam_ensemble(args, model, visual_input, text_input, tokenized_text, drop_iter=0)`
+    -> (gradcam_blocklist[layer][head] -> CPU (B,L-1,P,P) fp32, [], logits)
+                                                                    (blip_image_text_matching.py:386-457)
+  * `Inference_BLIP_filteredcaption`-equivalent `drop_loop` and the batch segmenter that replaces
+    save_img_union_attention's device work                          (PnP.py:290-521, 564-722)
+There is no eager / CPU fallback: every tensor op below is plumbing around pnp_ovss.hip.Engine.
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from . import config as C
+from . import host
+from . import synth
+from .hip import Engine
+from .tokenizer import SynthTokenizer, WordPieceTokenizer
+
+
+class _CrossSelf:
+    """`layer[i].crossattention.self` accessor object (med.py:162-180)."""
+
+    def __init__(self, model, idx):
+        self._m, self._i = model, idx
+        self.save_attention = False
+
+    def _check(self):
+        if self._i != self._m.engine.stash_layer:
+            raise RuntimeError(f"the engine keeps cross-attention maps for text layer {self._m.engine.stash_layer} only "
+                               f"(max_att_block_num - 1); re-create the model with stash_layer={self._i}")
+
+    def get_attention_map(self):
+        self._check()
+        return self._m._stash("P")
+
+    def get_attn_gradients(self):
+        self._check()
+        return self._m._stash("dP")
+
+
+class _Obj:
+    pass
+
+
+class BlipITM:
+    """BLIP image-text matching model whose forward / GradCAM run in libpnp_hip.so."""
+
+    def __init__(self, cfg, engine, tokenizer):
+        self.cfg, self.engine, self.tokenizer = cfg, engine, tokenizer
+        self.max_txt_len = 500                                     # blip_image_text_matching.py:48
+        layers = []
+        for i in range(cfg.txt_layers):
+            lay = _Obj()
+            lay.crossattention = _Obj()
+            lay.crossattention.self = _CrossSelf(self, i)
+            layers.append(lay)
+        enc = _Obj()
+        enc.layer = layers
+        bm2 = _Obj()
+        bm2.encoder = enc
+        bm1 = _Obj()
+        bm1.base_model = bm2
+        self.text_encoder = _Obj()
+        self.text_encoder.base_model = bm1
+        self.visual_encoder = _Obj()
+        self.visual_encoder.vision_width = cfg.vit_dim
+        self.module = self                                         # DDP-wrapper attribute the driver dereferences
+        self._last = None
+
+    # nn.Module-ish no-ops the driver calls
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def zero_grad(self):
+        pass
+
+    @property
+    def device(self):
+        return self.engine.device
+
+    def _tok_longest(self, captions):
+        return self.tokenizer(captions, padding="longest", truncation=True, max_length=self.max_txt_len,
+                              return_tensors="pt")
+
+    def _stash(self, name):
+        B, L = self._last
+        N, nst = self.cfg.n_img_tokens, (self.cfg.n_img_tokens + 63) // 64 * 64
+        flat = self.engine.buffer(name)
+        return flat[: B * self.cfg.txt_heads * L * nst].view(B, self.cfg.txt_heads, L, nst)[..., :N]
+
+    def __call__(self, samples, match_head="itm"):
+        """BlipITM.forward(match_head="itm") (blip_image_text_matching.py:217-249) -> logits (B,2)."""
+        if match_head != "itm":
+            raise NotImplementedError("only the ITM head is on the hot path")
+        image = samples["image"].to(self.device, torch.float32).contiguous()
+        text = self._tok_longest(samples["text_input"]).to(self.device)
+        L = text.input_ids.shape[1]
+        self.engine.vit_forward(image)
+        logits = self.engine.text_forward(text.input_ids.contiguous(), text.attention_mask.contiguous(), L)
+        self._last = (image.shape[0], L)
+        return logits
+
+
+class _LazyHeads:
+    def __init__(self, fn):
+        self._fn, self._cache = fn, {}
+
+    def __getitem__(self, head):
+        if head not in self._cache:
+            self._cache[head] = self._fn(head)
+        return self._cache[head]
+
+    def __len__(self):
+        return 12
+
+
+class _LazyBlocks:
+    """gradcam_blocklist[layer][head]: materialised on demand (the reference builds all 144 maps and
+    the driver reads one, PnP.py:619-621)."""
+
+    def __init__(self, model, mask, L):
+        self._m, self._mask, self._L = model, mask, L
+
+    def __getitem__(self, layer):
+        eng = self._m.engine
+        if layer != eng.stash_layer:
+            raise RuntimeError(f"GradCAM maps are kept for text layer {eng.stash_layer} only; "
+                               f"re-create the model with stash_layer={layer}")
+        return _LazyHeads(lambda h: eng.gradcam_gather(self._mask, self._L, h).cpu())
+
+    def __len__(self):
+        return 12
+
+
+def compute_gradcam_ensemble(args, model, visual_input, text_input, tokenized_text, drop_iter=0):
+    """Drop-in for blip_image_text_matching.py:386-457."""
+    m = model.module if hasattr(model, "module") else model
+    eng = m.engine
+    image = visual_input.to(m.device, torch.float32).contiguous()
+    text = m._tok_longest(text_input).to(m.device)
+    L = text.input_ids.shape[1]
+    B = image.shape[0]
+    eng.vit_forward(image)
+    logits = eng.text_forward(text.input_ids.contiguous(), text.attention_mask.contiguous(), L)
+    eng.xattn_grad(B, L)
+    m._last = (B, L)
+    mask = tokenized_text.attention_mask.to(m.device).contiguous()          # the caller's 500-padded mask (:415-416)
+    return _LazyBlocks(m, mask, L), [], logits
+
+
+def drop_loop(args, model, txt_tokens, imgs_in, caption_list):
+    """Inference_BLIP_filteredcaption (PnP.py:564-722): returns (gradcam_0, gradcam_agg) on device."""
+    m = model.module if hasattr(model, "module") else model
+    image = imgs_in.to(m.device, torch.float32).contiguous()
+    text = m._tok_longest(caption_list).to(m.device)
+    L = text.input_ids.shape[1]
+    mask = txt_tokens.attention_mask.to(m.device).contiguous()
+    ids = txt_tokens.input_ids.to(m.device).contiguous()
+    g0, agg, picks, _ = m.engine.drop_loop(image, ids, mask, L, int(args.prune_att_head), int(args.drop_iter))
+    m._last = (image.shape[0], L)
+    return g0, agg
+
+
+def _resize_pos_embed(pos, n_new_grid):
+    """interpolate_pos_embed (base_model.py:44-73): bicubic, align_corners=False, cls token kept."""
+    pos = torch.as_tensor(pos, dtype=torch.float32)
+    D = pos.shape[-1]
+    n_old = int((pos.shape[-2] - 1) ** 0.5)
+    if n_old == n_new_grid:
+        return pos
+    extra, grid = pos[:, :1], pos[:, 1:]
+    grid = grid.reshape(-1, n_old, n_old, D).permute(0, 3, 1, 2)
+    grid = torch.nn.functional.interpolate(grid, size=(n_new_grid, n_new_grid), mode="bicubic", align_corners=False)
+    grid = grid.permute(0, 2, 3, 1).flatten(1, 2)
+    return torch.cat((extra, grid), dim=1)
+
+
+def build_model(model_type="large", img_size=336, device=0, max_batch=35, max_text_len=64, stash_layer=7, bf16=True,
+                checkpoint=None, vocab=None, seed=0, cfg=None):
+    """from_config + load_checkpoint (blip_image_text_matching.py:297-314, base_model.py:86-125)."""
+    if cfg is None:
+        if model_type != "large":
+            raise ValueError("only blip_image_text_matching/large is on the hot path")
+        cfg = C.blip_itm_large(img_size)
+    checkpoint = checkpoint or os.environ.get("PNP_OVSS_CHECKPOINT")
+    vocab = vocab or os.environ.get("PNP_OVSS_VOCAB")
+    dev = device if isinstance(device, int) else (torch.device(device).index or 0)
+    eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len, stash_layer=stash_layer, bf16=bf16, device=dev)
+    if checkpoint:
+        sd = torch.load(checkpoint, map_location="cpu")
+        sd = sd["model"] if "model" in sd else sd
+        sd["visual_encoder.pos_embed"] = _resize_pos_embed(sd["visual_encoder.pos_embed"], cfg.grid)
+        shapes = synth.param_shapes(cfg)
+        sd = {k: v for k, v in sd.items() if k in shapes and tuple(v.shape) == tuple(shapes[k])}   # :116-119
+        eng.load_state_dict(sd)
+    else:
+        warnings.warn("no BLIP checkpoint given (PNP_OVSS_CHECKPOINT): using seeded synthetic weights")
+        eng.load_state_dict(synth.synth_state_dict(cfg, seed))
+    tok = WordPieceTokenizer(vocab) if vocab else SynthTokenizer(cfg.vocab)
+    return BlipITM(cfg, eng, tok)
+
+
+class Segmenter:
+    """Device work of save_img_union_attention (PnP.py:290-521) for one batch: drop loop, merge,
+    threshold/upsample, blur, CRF, argmax/remap, histogram."""
+
+    def __init__(self, model, data_type, n_class, threshold=0.15, postprocess="blur+crf", max_pixels_per_image=600 * 600,
+                 max_channels=24, crf_chunk=0):
+        self.m = model.module if hasattr(model, "module") else model
+        self.data_type, self.n_class, self.threshold, self.mode = data_type, n_class, threshold, postprocess
+        eng = self.m.engine
+        eng.post_reserve(eng.max_batch, eng.max_batch * max_pixels_per_image, max_pixels_per_image, max_channels, crf_chunk)
+        self.hist_1drop = torch.zeros(n_class * n_class, device=eng.device, dtype=torch.int64)
+        self.hist_ndrop = torch.zeros(n_class * n_class, device=eng.device, dtype=torch.int64)
+
+    def run(self, args, imgs_in, captions, best_class_idx, org_images, label_trues, run_1drop=True):
+        m, eng = self.m, self.m.engine
+        dev = eng.device
+        tok500 = m.tokenizer(captions, padding="max_length", max_length=500, return_tensors="pt")
+        g0, agg = drop_loop(args, m, tok500, imgs_in, captions)
+        ids = tok500.input_ids.numpy()
+        sizes = [(int(x.shape[0]), int(x.shape[1])) for x in org_images]
+        plans, luts, bgs = [], [], []
+        for i, best in enumerate(best_class_idx):
+            pieces = host.caption_pieces(m.tokenizer, ids[i])
+            bg = host.has_background(self.data_type, len(best))
+            plans.append(host.merge_plan(pieces, len(best)))
+            luts.append(host.remap_lut(best, bg, len(best) + int(bg)))
+            bgs.append(bg)
+        rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(x, dtype=np.uint8).reshape(-1) for x in org_images])).to(dev)
+        gt = None
+        if label_trues is not None:
+            gt = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in label_trues])).to(dev)
+        eng.post_prepare(sizes, plans, luts, bgs, rgb=rgb, gt=gt, want_crf=bool(self.mode and "crf" in self.mode))
+        out1 = outn = None
+        if run_1drop or agg is None:
+            out1 = eng.split_labels(eng.postprocess(g0, self.threshold, True, self.mode, self.n_class, self.hist_1drop))
+        if agg is not None:
+            outn = eng.split_labels(eng.postprocess(agg, self.threshold, False, self.mode, self.n_class, self.hist_ndrop))
+        return out1, outn

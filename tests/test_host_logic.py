@@ -1,0 +1,129 @@
+"""CPU: the product's host-side logic (pnp_ovss.host / tokenizer / datasets sharding) against the
+golden vectors produced by the reference and against the oracle; multi-rank pieces over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pnp_ovss import host
+from pnp_ovss.tokenizer import SynthTokenizer
+from oracle import pipeline_np as OP
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_parse_gpt_matches_reference(golden_dir):
+    data = json.load(open(os.path.join(golden_dir, "gpt_parse.json")))
+    for dt, d in data.items():
+        for k, case in d["cases"].items():
+            if "error" in case:
+                with pytest.raises(Exception):
+                    host.parse_gpt_classes(case["raw"], d["nms"])
+                continue
+            best, names, cap = host.parse_gpt_classes(case["raw"], d["nms"])
+            assert (best, names, cap) == (case["best_class_idx"], case["classes"], case["caption"]), k
+
+
+def test_merge_plan_reproduces_reference_merge(golden_dir):
+    g = np.load(os.path.join(golden_dir, "merge_tokens.npz"))
+    pieces = json.loads(str(g["pieces"]))
+    tok = SynthTokenizer(1024)
+    for i, cap in enumerate(str(c) for c in g["captions"]):
+        n_cls = len(cap.split()[3:])
+        enc = tok([cap], padding="max_length", max_length=500)
+        pc = host.caption_pieces(tok, enc.input_ids[0].numpy())
+        assert pc == pieces[i][4:-1]
+        plan = host.merge_plan(pc, n_cls)
+        src = g["maps"][i][3:-1]
+        out = np.zeros((n_cls,) + src.shape[1:], np.float32)
+        for c, (toks, div) in enumerate(plan):
+            if toks:
+                acc = src[toks[0]].copy()
+                for t in toks[1:]:
+                    acc = (acc + src[t]).astype(np.float32)
+                out[c] = acc / np.float32(div) if div != 1 else acc
+        np.testing.assert_array_equal(out, g[f"merged_{i}"])
+
+
+def test_remap_lut_equals_sequential_remap():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        n = int(rng.integers(1, 8))
+        best = [int(v) for v in rng.integers(0, 9, size=n)]          # small ids force index/id collisions
+        for bg in (True, False):
+            K = n + int(bg)
+            lab = rng.integers(0, K, size=(13, 7)).astype(np.float32)
+            lut = np.array(host.remap_lut(best, bg, K))
+            np.testing.assert_array_equal(lut[lab.astype(int)].astype(np.float32), OP.remap_labels(lab, best, bg))
+
+
+def test_shard_indices_matches_distributed_sampler():
+    torch = pytest.importorskip("torch")
+    from torch.utils.data.distributed import DistributedSampler
+    for n, w in [(1449, 8), (10, 4), (7, 2), (5, 8)]:
+        seen = []
+        for r in range(w):
+            ref = list(DistributedSampler(range(n), num_replicas=w, rank=r))
+            assert host.shard_indices(n, r, w) == ref
+            seen += ref
+        assert set(seen) == set(range(n))
+
+
+def test_scores_from_hist_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hist_cases.npz"))
+    s = host.scores_from_hist(g["hist"])
+    assert s["Mean IoU"] == float(g["miou"]) and s["Pixel Accuracy"] == float(g["pixacc"])
+    assert s["Frequency Weighted IoU"] == float(g["fwiou"]) and s["Mean Accuracy"] == float(g["macc"])
+
+
+def test_gaussian_taps_equal_scipy_kernel():
+    from pnp_ovss.hip import gaussian_taps
+    from scipy.ndimage import _filters
+    for h, w in [(336, 336), (375, 500), (768, 768), (33, 21)]:
+        sigma = 0.05 * max(h, w)
+        radius = int(4.0 * sigma + 0.5)
+        ref = _filters._gaussian_kernel1d(sigma, 0, radius)[::-1]
+        np.testing.assert_array_equal(gaussian_taps(h, w), ref[radius:])
+
+
+_GLOO_WORKER = r'''
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "pnp-ovss_amd"))
+from pnp_ovss import host
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n = 11
+idx = host.shard_indices(n, rank, world)
+# each rank "segments" its shard: histogram of (gt, pred) pairs derived from the image index
+hist = torch.zeros(21 * 21, dtype=torch.int64)
+for i in idx:
+    hist[(i % 21) * 21 + (3 * i) % 21] += 1
+labels = torch.tensor(idx, dtype=torch.uint8)
+dist.all_reduce(hist)                                   # the reduce bench.py / the CLI do over RCCL
+gathered = [torch.empty_like(labels) for _ in range(world)] if rank == 0 else None
+dist.gather(labels, gathered, dst=0)                    # mask-gather to rank 0
+flat = torch.tensor([float(rank + 1)] * 5)
+dist.broadcast(flat, src=0)                             # weight broadcast from rank 0
+if rank == 0:
+    print(json.dumps({"hist_sum": int(hist.sum()), "gathered": [g.tolist() for g in gathered], "bcast": flat.tolist()}))
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_sharding_reduce_gather_over_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER)
+    port = 29500 + os.getpid() % 2000
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["hist_sum"] == 12                         # 11 images padded to 12 (one duplicate), like the reference sampler
+    assert sorted(res["gathered"][0] + res["gathered"][1]) == sorted(host.shard_indices(11, 0, 2) + host.shard_indices(11, 1, 2))
+    assert res["bcast"] == [1.0] * 5
