@@ -288,72 +288,86 @@ __global__ void crf_norm_kernel(const CrfLattice L, const PostDesc* __restrict__
 // every access is one 16-byte vector per lane (pad channels carry zeros and are never read back as
 // labels).  Arithmetic per channel is exactly the scalar sequence of the oracle.
 //
+// Work distribution of the iteration kernels: workgroups with the same blockIdx % 8 share an XCD
+// (round-robin dispatch; a speed assumption only), so each XCD is given whole images (b = xcd,
+// xcd + 8, ...) and sweeps them one after another: the ~10 MB value rows of the image an XCD is
+// working on are re-read (neighbour / contributor gathers) out of L2 / Infinity Cache instead of HBM.
+// Inside an image 8 lanes share one lattice point (one 16-byte channel chunk each).
+//
 // splat: val[id] = sum over the lattice point's contributors (ascending pixel) of bary * (Q * norm)
-__global__ void crf_splat4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ Q,
-                                  const float* __restrict__ norm, float* __restrict__ val, int img0) {
-    const int b = img0 + blockIdx.y;
-    const PostDesc im = imgs[b];
-    const int K4 = im.Kp >> 2;
-    const int lo = L.idbase[b], hi = L.idbase[b + 1];
-    const f32x4* Q4 = reinterpret_cast<const f32x4*>(Q + im.qoff);
-    f32x4* V4 = reinterpret_cast<f32x4*>(val + im.voff[L.which]);
-    const int total = (hi - lo) * K4;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int idl = t / K4, c = t - idl * K4;
-        const int e0 = L.seg_start[lo + idl], e1 = L.seg_start[lo + idl + 1];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int e = e0; e < e1; e += 4) {
-            // issue up to four independent gathers before the ordered accumulation
-            uint32_t pv[4];
-            f32x4 in[4];
-            float w[4], nr[4];
+template <int D1>
+__global__ __launch_bounds__(256) void crf_splat4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
+                                                         const float* __restrict__ Q, const float* __restrict__ norm,
+                                                         float* __restrict__ val, int img0, int nimg) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int c0 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
+        const PostDesc im = imgs[b];
+        const int K4 = im.Kp >> 2;
+        const int lo = L.idbase[b], hi = L.idbase[b + 1];
+        const f32x4* Q4 = reinterpret_cast<const f32x4*>(Q + im.qoff);
+        f32x4* V4 = reinterpret_cast<f32x4*>(val + im.voff[L.which]);
+        for (int idl = slot * 32 + pl; idl < hi - lo; idl += bpx * 32) {
+            const int e0 = L.seg_start[lo + idl], e1 = L.seg_start[lo + idl + 1];
+            for (int c = c0; c < K4; c += 8) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int e = e0; e < e1; e += 4) {
+                    // issue up to four independent gathers before the ordered accumulation
+                    const int n = e1 - e;
+                    uint32_t pv[4];
+                    f32x4 in[4];
+                    float w[4], nr[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int ee = (e + j < e1) ? e + j : e1 - 1;
-                pv[j] = L.vals[ee];
-            }
+                    for (int j = 0; j < 4; j++) pv[j] = L.vals[j < n ? e + j : e];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t pixel = pv[j] / (uint32_t)L.D1;
-                in[j] = Q4[(size_t)(pixel - im.pix0) * K4 + c];
-                nr[j] = norm[pixel];
-                w[j] = L.bary[pv[j]];
-            }
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t pixel = pv[j] / (uint32_t)D1;
+                        in[j] = Q4[(size_t)(pixel - im.pix0) * K4 + c];
+                        nr[j] = norm[pixel];
+                        w[j] = L.bary[pv[j]];
+                    }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (e + j < e1) {
+                    for (int j = 0; j < 4; j++) {
+                        if (j < n) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) acc[i] = __fadd_rn(acc[i], __fmul_rn(w[j], __fmul_rn(in[j][i], nr[j])));
+                            for (int i = 0; i < 4; i++) acc[i] = __fadd_rn(acc[i], __fmul_rn(w[j], __fmul_rn(in[j][i], nr[j])));
+                        }
+                    }
                 }
+                V4[(size_t)idl * K4 + c] = acc;
             }
         }
-        V4[(size_t)idl * K4 + c] = acc;
     }
 }
 
 // one axis of the lattice blur: new = old + 0.5 * (n1 + n2), absent neighbours contribute 0
-__global__ void crf_blur4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, const float* __restrict__ src,
-                                 float* __restrict__ dst, int axis, int img0) {
-    const int b = img0 + blockIdx.y;
-    const PostDesc im = imgs[b];
-    const int K4 = im.Kp >> 2;
-    const int lo = L.idbase[b], hi = L.idbase[b + 1];
-    const f32x4* S4 = reinterpret_cast<const f32x4*>(src + im.voff[L.which]);
-    f32x4* D4 = reinterpret_cast<f32x4*>(dst + im.voff[L.which]);
+__global__ __launch_bounds__(256) void crf_blur4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
+                                                        const float* __restrict__ src, float* __restrict__ dst, int axis,
+                                                        int img0, int nimg) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+    const int c0 = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int* n1 = L.n1 + (size_t)axis * L.cap;
     const int* n2 = L.n2 + (size_t)axis * L.cap;
-    const int total = (hi - lo) * K4;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
-        const int idl = t / K4, c = t - idl * K4;
-        const int a = n1[lo + idl], d = n2[lo + idl];
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 va = a >= 0 ? S4[(size_t)(a - lo) * K4 + c] : zero;
-        const f32x4 vd = d >= 0 ? S4[(size_t)(d - lo) * K4 + c] : zero;
-        const f32x4 old = S4[(size_t)idl * K4 + c];
-        f32x4 o;
+    for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
+        const PostDesc im = imgs[b];
+        const int K4 = im.Kp >> 2;
+        const int lo = L.idbase[b], hi = L.idbase[b + 1];
+        const f32x4* S4 = reinterpret_cast<const f32x4*>(src + im.voff[L.which]);
+        f32x4* D4 = reinterpret_cast<f32x4*>(dst + im.voff[L.which]);
+        for (int idl = slot * 32 + pl; idl < hi - lo; idl += bpx * 32) {
+            const int a = n1[lo + idl], d = n2[lo + idl];
+            for (int c = c0; c < K4; c += 8) {
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 va = a >= 0 ? S4[(size_t)(a - lo) * K4 + c] : zero;
+                const f32x4 vd = d >= 0 ? S4[(size_t)(d - lo) * K4 + c] : zero;
+                const f32x4 old = S4[(size_t)idl * K4 + c];
+                f32x4 o;
 #pragma unroll
-        for (int i = 0; i < 4; i++) o[i] = (float)__dadd_rn((double)old[i], __dmul_rn(0.5, (double)__fadd_rn(va[i], vd[i])));
-        D4[(size_t)idl * K4 + c] = o;
+                for (int i = 0; i < 4; i++)
+                    o[i] = (float)__dadd_rn((double)old[i], __dmul_rn(0.5, (double)__fadd_rn(va[i], vd[i])));
+                D4[(size_t)idl * K4 + c] = o;
+            }
+        }
     }
 }
 
@@ -513,12 +527,15 @@ int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
                float* va, float* vb, const float** result, hipStream_t s) {
     const int D = L.D1 - 1;
-    const int nb = L.which == 0 ? 256 : 2048;
-    hipLaunchKernelGGL(crf_splat4_kernel, dim3(nb, nimg), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0);
+    const int nb = 8 * (L.which == 0 ? 64 : 256);          // 8 XCD groups x workgroups per XCD
+    if (L.D1 == 3)
+        hipLaunchKernelGGL((crf_splat4_kernel<3>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, nimg);
+    else
+        hipLaunchKernelGGL((crf_splat4_kernel<6>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, nimg);
     float* src = va;
     float* dst = vb;
     for (int j = 0; j <= D; j++) {
-        hipLaunchKernelGGL(crf_blur4_kernel, dim3(nb, nimg), dim3(256), 0, s, L, d_imgs, src, dst, j, img0);
+        hipLaunchKernelGGL(crf_blur4_kernel, dim3(nb), dim3(256), 0, s, L, d_imgs, src, dst, j, img0, nimg);
         float* t = src;
         src = dst;
         dst = t;
