@@ -20,7 +20,12 @@ namespace pnp {
 
 template <int D> struct KeyPack;
 template <> struct KeyPack<2> { static constexpr int BITS = 16; };
-template <> struct KeyPack<5> { static constexpr int BITS = 12; };
+template <> struct KeyPack<5> { static constexpr int BITS = 11; };
+// The image index of the batch is placed above the coordinate bits (bit IMG_SHIFT..), so ONE
+// device-wide stable radix sort groups the entries of every image (a segmented sort with a few huge
+// segments is several times slower).  5 x 11 + 6 bits <= 61: at most 64 images per prepared batch.
+constexpr int IMG_SHIFT = 55;
+constexpr int IMG_BITS = 6;
 
 template <int D>
 __device__ __forceinline__ uint64_t pack_key(const int* c) {
@@ -35,7 +40,7 @@ __device__ __forceinline__ void unpack_key(uint64_t k, int* c) {
     constexpr int BITS = KeyPack<D>::BITS;
 #pragma unroll
     for (int i = D - 1; i >= 0; i--) {
-        c[i] = (int)(k & ((1 << BITS) - 1)) - (1 << (BITS - 1));
+        c[i] = (int)(k & ((1 << BITS) - 1)) - (1 << (BITS - 1));      // image bits above D*BITS are ignored
         k >>= BITS;
     }
 }
@@ -141,7 +146,7 @@ __global__ void lattice_embed_kernel(const PostDesc* __restrict__ imgs, const ui
                 bad |= (key[i] <= -(1 << (KeyPack<D>::BITS - 1)) + D + 1) || (key[i] >= (1 << (KeyPack<D>::BITS - 1)) - D - 1);
             }
             if (bad) atomicExch(range_err, 1);
-            keys[e0 + rem] = pack_key<D>(key);
+            keys[e0 + rem] = pack_key<D>(key) | ((uint64_t)b << IMG_SHIFT);
             vals[e0 + rem] = (uint32_t)(e0 + rem);
             bary[e0 + rem] = barycentric[rem];
         }
@@ -215,7 +220,7 @@ __global__ void neighbors_kernel(const uint64_t* __restrict__ ukeys, const int* 
                 in2 &= (d2[k] >= -(1 << (BITS - 1)) && d2[k] < (1 << (BITS - 1)));
             }
             if (in1) {
-                const uint64_t k1 = pack_key<D>(a);
+                const uint64_t k1 = pack_key<D>(a) | ((uint64_t)b << IMG_SHIFT);
                 int l = lo, h = hi;
                 while (l < h) {
                     const int mid = (l + h) >> 1;
@@ -225,7 +230,7 @@ __global__ void neighbors_kernel(const uint64_t* __restrict__ ukeys, const int* 
                 if (l < hi && ukeys[l] == k1) r1 = l;
             }
             if (in2) {
-                const uint64_t k2 = pack_key<D>(d2);
+                const uint64_t k2 = pack_key<D>(d2) | ((uint64_t)b << IMG_SHIFT);
                 int l = lo, h = hi;
                 while (l < h) {
                     const int mid = (l + h) >> 1;
@@ -464,9 +469,9 @@ static inline int ok() { return hipGetLastError() == hipSuccess ? PNP_OK : PNP_E
 
 size_t crf_sort_temp_bytes(size_t max_entries, int max_images) {
     size_t a = 0, b = 0;
-    (void)hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                                (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)max_entries, max_images,
-                                                (const int*)nullptr, (const int*)nullptr, 0, 64, 0);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)max_entries, 0, 64, 0);
+    (void)max_images;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int*)nullptr, (int*)nullptr, (int)max_entries, 0);
     return (a > b ? a : b) + 256;
 }
@@ -484,10 +489,15 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
         hipLaunchKernelGGL((lattice_embed_kernel<5>), dim3(nb, B), dim3(256), 0, s, d_imgs, d_rgb, sxy, srgb, L.bary, keys_a, vals_a, d_range_err);
     else
         return PNP_ERR_ARG;
-    const int bits = D == 2 ? 32 : 60;
+    if (B > (1 << IMG_BITS)) return PNP_ERR_ARG;
+    (void)d_seg_begin;
+    (void)d_seg_end;
+    // bits actually populated: coordinates (D * BITS, low) + image index (IMG_SHIFT..)
+    int img_bits = 0;
+    while ((1 << img_bits) < B) img_bits++;
+    const int end_bit = B > 1 ? IMG_SHIFT + img_bits : (D == 2 ? 32 : 55);
     size_t tb = temp_bytes;
-    if (hipcub::DeviceSegmentedRadixSort::SortPairs(temp, tb, keys_a, keys_b, vals_a, L.vals, (int)ent_total, B, d_seg_begin,
-                                                    d_seg_end, 0, bits, s) != hipSuccess)
+    if (hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_a, keys_b, vals_a, L.vals, (int)ent_total, 0, end_bit, s) != hipSuccess)
         return PNP_ERR_HIP;
     const int nbe = 1024;
     hipLaunchKernelGGL(mark_heads_kernel, dim3(nbe, B), dim3(256), 0, s, keys_b, d_imgs, D + 1, head);

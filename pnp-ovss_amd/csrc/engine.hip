@@ -828,8 +828,9 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
                                 int32_t max_channels, int32_t crf_chunk) {
     if (!e) return PNP_ERR_ARG;
     if (e->post.reserved) return fail(e, PNP_ERR_STATE, "post-process workspace already reserved");
-    if (max_batch <= 0 || max_total_pixels <= 0 || max_pixels_per_image <= 0 || max_channels <= 0 || max_channels > 255)
-        return fail(e, PNP_ERR_ARG, "bad post-process bounds");
+    if (max_batch <= 0 || max_batch > 64 || max_total_pixels <= 0 || max_pixels_per_image <= 0 || max_channels <= 0 ||
+        max_channels > 255)
+        return fail(e, PNP_ERR_ARG, "bad post-process bounds (at most 64 images per batch, 255 channels)");
     HIPCHK(e, hipSetDevice(e->c.device));
     auto& p = e->post;
     p.maxB = max_batch;
