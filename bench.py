@@ -170,7 +170,7 @@ def main():
                                    "BLIP-ITM-large random weights, layer 8 head 9, drop_iter 4, threshold 0.15, "
                                    + ("N-drop" if a.skip_1drop else "1-drop + N-drop") + " blur+CRF",
                        "images_per_step_per_gpu": B, "sharding": "images across ranks, no per-step collective"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_big_kernel<{a.dtype}> (256x128 tile, LDS-DMA ring)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_big_kernel<{a.dtype},128,128,64,64,2> (LDS-DMA ring GEMM)", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                          "launches": launches, "avg_launch_ms": ms / max(launches, 1),
                          "algorithmic_flop_per_launch": flops / max(launches, 1)},

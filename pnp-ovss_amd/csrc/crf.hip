@@ -537,7 +537,7 @@ int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
                float* va, float* vb, const float** result, hipStream_t s) {
     const int D = L.D1 - 1;
-    const int nb = 8 * (L.which == 0 ? 64 : 256);          // 8 XCD groups x workgroups per XCD
+    const int nb = 8 * 256;                                 // 8 XCD groups x 256 resident workgroups per XCD
     if (L.D1 == 3)
         hipLaunchKernelGGL((crf_splat4_kernel<3>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, nimg);
     else

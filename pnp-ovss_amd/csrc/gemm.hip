@@ -11,6 +11,8 @@
 // reads (16 consecutive rows, same logical chunk) are conflict-free ds_read_b128.
 // Operands are swapped at the MFMA (D = Btile * Atile^T) so each lane owns 4 CONSECUTIVE output
 // columns of one row: the epilogue does one 8/16-byte store per fragment and vector bias loads.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -69,7 +71,7 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, 
     if (g.mode == GEMM_EPI_GELU) {
         if (g.aux) *reinterpret_cast<f32x4*>(g.aux + (size_t)orow * g.ld_aux + n) = v;
 #pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = gelu_erf(v[e]);
+        for (int e = 0; e < 4; e++) v[e] = sizeof(T) == 2 ? gelu_erf_fast(v[e]) : gelu_erf(v[e]);
     } else if (g.mode == GEMM_EPI_GELU_GRAD) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(g.aux + (size_t)orow * g.ld_aux + n);
 #pragma unroll
@@ -122,57 +124,62 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, 
 // ring so two k-slabs are always in flight; one raw s_barrier per k-slab with a COUNTED vmcnt
 // (never 0 in the main loop).  The LDS image is lane-linear per DMA (8 rows x 128 B), so the XOR
 // swizzle is applied to the per-lane SOURCE address and again on the fragment read.
-constexpr int BIG_BM = 256, BIG_BN = 128, BIG_NS = 3;
+#define PNP_WAIT_VM_LGKM(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
+#define PNP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <typename T>
-__global__ __launch_bounds__(512) void gemm_nt_big_kernel(const GemmArgs g) {
+// BM x BN block tile, (BM/WTM) x (BN/WTN) waves of WTM x WTN, NS-slot LDS ring.
+template <typename T, int BM, int BN, int WTM, int WTN, int NS>
+__global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kernel(const GemmArgs g) {
     constexpr int ROWB = 128;
     constexpr int BK = ROWB / Elem<T>::kBytes;
-    constexpr int BM = BIG_BM, BN = BIG_BN, NS = BIG_NS;
-    constexpr int STAGE = (BM + BN) * ROWB;          // 48 KB
-    constexpr int TM = 4, TN = 4;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int WN = BN / WTN, NWAVES = (BM / WTM) * WN;
+    constexpr int MFMA_PER_READ = (TM * TN) / (TM + TN);
+    constexpr int A_DMA = BM / 8 / NWAVES, B_DMA = BN / 8 / NWAVES, NDMA = A_DMA + B_DMA;   // per wave per slab
+    static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     int bm, bn;
-    tile_coords<4>(blockIdx.x, nbm, nbn, bm, bn);
+    tile_coords<(BM >= 256 ? 4 : 8)>(blockIdx.x, nbm, nbn, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
 
-    // DMA assignment: wave w moves A rows [32w, 32w+32) (4 DMAs of 8 rows) and B rows [16w, 16w+16) (2 DMAs)
-    const char* src[6];
-    int dst[6];
+    // DMA assignment: wave w moves A rows [8*A_DMA*w, ..) and B rows [8*B_DMA*w, ..), 8 rows per DMA
+    const char* src[NDMA];
+    int dst[NDMA];
     {
         const char* Ab = reinterpret_cast<const char*>(g.A);
         const char* Bb = reinterpret_cast<const char*>(g.B);
         const size_t lda_b = (size_t)g.lda * Elem<T>::kBytes, ldb_b = (size_t)g.ldb * Elem<T>::kBytes;
         const int pc = lane & 7;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int row = wave * 32 + i * 8 + (lane >> 3);
+        for (int i = 0; i < A_DMA; i++) {
+            const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
             int gr = m0 + row;
             gr = gr < g.M ? gr : g.M - 1;
             src[i] = Ab + (size_t)gr * lda_b + swz_chunk<ROWB>(row, pc) * 16;
-            dst[i] = (wave * 32 + i * 8) * ROWB;                       // wave-uniform DMA base
+            dst[i] = (wave * A_DMA + i) * 8 * ROWB;                    // wave-uniform DMA base
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int row = wave * 16 + i * 8 + (lane >> 3);
+        for (int i = 0; i < B_DMA; i++) {
+            const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
             int gr = n0 + row;
             gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
-            src[4 + i] = Bb + (size_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
-            dst[4 + i] = BM * ROWB + (wave * 16 + i * 8) * ROWB;
+            src[A_DMA + i] = Bb + (size_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
+            dst[A_DMA + i] = BM * ROWB + (wave * B_DMA + i) * 8 * ROWB;
         }
     }
     auto issue = [&](int kt) {
         char* stage = smem + (kt % NS) * STAGE;
         const size_t koff = (size_t)kt * ROWB;
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < NDMA; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
                                              (__attribute__((address_space(3))) void*)(stage + dst[i]), 16, 0, 0);
     };
@@ -189,9 +196,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const GemmArgs g) {
         const char* cA = smem + (kt % NS) * STAGE;
         const char* cB = cA + BM * ROWB;
 #pragma unroll
-        for (int j = 0; j < TM; j++) lds_frag<ROWB>(fa[j], cA, wm * 64 + j * 16 + r, ks, q);
+        for (int j = 0; j < TM; j++) lds_frag<ROWB>(fa[j], cA, wm * WTM + j * 16 + r, ks, q);
 #pragma unroll
-        for (int i = 0; i < TN; i++) lds_frag<ROWB>(fb[i], cB, wn * 64 + i * 16 + r, ks, q);
+        for (int i = 0; i < TN; i++) lds_frag<ROWB>(fb[i], cB, wn * WTN + i * 16 + r, ks, q);
     };
     auto mma_step = [&](const Frag<T>* fa, const Frag<T>* fb) {
 #pragma unroll
@@ -202,14 +209,16 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const GemmArgs g) {
     if constexpr (KSTEPS == 2) {
         // Pipeline (bf16): every MFMA cluster overlaps the fragment reads of the NEXT k-step, and the
         // slab hand-over (counted vmcnt + one s_barrier + next DMA issue) sits between two clusters
-        // whose operands are already in registers.  Slabs kt+1 (landed), kt+2 (in flight) and kt+3
-        // (just issued into slab kt's slot, whose data is fully in registers) share the 3-slot ring.
-        issue(0);
-        if (nk > 1) issue(1);
-        if (nk > 2) issue(2);
-        if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // whose operands are already in registers.  After the barrier of iteration kt slab kt lives
+        // entirely in registers, so its ring slot is refilled with slab kt+NS: slabs kt+1 (landed)
+        // .. kt+NS-1 (in flight) occupy the other slots.
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+            if (i < nk) issue(i);
+        // slab 0 landed: at most min(NS, nk) - 1 younger slabs may stay in flight
+        if (nk >= NS) PNP_WAIT_VM((NS - 1) * NDMA);
+        else if (NS > 2 && nk == NS - 1) PNP_WAIT_VM((NS > 2 ? NS - 2 : 0) * NDMA);
+        else PNP_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
         Frag<T> fa0[TM], fb0[TN], fa1[TM], fb1[TN];
         read_frags(fa0, fb0, 0, 0);
@@ -217,21 +226,21 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const GemmArgs g) {
             read_frags(fa1, fb1, kt, 1);
             mma_step(fa0, fb0);
 #pragma unroll
-            for (int x = 0; x < 8; x++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // 2 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+            for (int x = 0; x < TM + TN; x++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER_READ, 0);   // MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // 1 DS read
             }
             if (kt + 1 < nk) {
-                // own reads of slab kt are complete, slab kt+1 has landed (kt+2 may stay in flight)
-                if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // own reads of slab kt are complete, slab kt+1 has landed (younger slabs stay in flight)
+                if (kt + NS - 1 < nk) PNP_WAIT_VM_LGKM((NS - 2) * NDMA);
+                else PNP_WAIT_VM_LGKM(0);
                 __builtin_amdgcn_s_barrier();
-                if (kt + 3 < nk) issue(kt + 3);
+                if (kt + NS < nk) issue(kt + NS);
                 read_frags(fa0, fb0, kt + 1, 0);
                 mma_step(fa1, fb1);
 #pragma unroll
-                for (int x = 0; x < 8; x++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                for (int x = 0; x < TM + TN; x++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER_READ, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             } else {
@@ -239,44 +248,52 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(const GemmArgs g) {
             }
         }
     } else {
+        // fp32 parity mode (one k-step per slab): simple ring, two slabs in flight at most
         issue(0);
-        if (nk > 1) issue(1);
+        if (nk > 1 && NS > 2) issue(1);
         for (int kt = 0; kt < nk; kt++) {
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (NS > 2 && kt + 1 < nk) PNP_WAIT_VM(NDMA);
+            else PNP_WAIT_VM(0);
             __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) issue(kt + 2);
+            if (NS > 2) {
+                if (kt + 2 < nk) issue(kt + 2);
+            } else if (kt + 1 < nk) {
+                issue(kt + 1);
+            }
             Frag<T> fa[TM], fb[TN];
             read_frags(fa, fb, kt, 0);
             mma_step(fa, fb);
+            if (NS == 2) {                     // the single spare slot is refilled next iteration: finish reading first
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < TM; j++) {
-        const int m = m0 + wm * 64 + j * 16 + r;
+        const int m = m0 + wm * WTM + j * 16 + r;
         if (m >= g.M) continue;
         const RowCtx rc = row_ctx(g, m);
 #pragma unroll
         for (int i = 0; i < TN; i++) {
-            const int n = n0 + wn * 64 + i * 16 + q * 4;
+            const int n = n0 + wn * WTN + i * 16 + q * 4;
             if (n >= g.Nvalid) continue;
             store_frag<T>(g, rc, acc[i][j], m, n);
         }
     }
 }
 
-template <typename T>
+template <typename T, int BM, int BN, int WTM, int WTN, int NS>
 static int launch_big(const GemmArgs& g, hipStream_t s) {
-    const int nbm = (g.M + BIG_BM - 1) / BIG_BM, nbn = g.N / BIG_BN;
-    const size_t smem = (size_t)BIG_NS * (BIG_BM + BIG_BN) * 128;
+    const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
+    const size_t smem = (size_t)NS * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return PNP_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_big_kernel<T>), dim3(nbm * nbn), dim3(512), smem, s, g);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS>), dim3(nbm * nbn), dim3((BM / WTM) * (BN / WTN) * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
@@ -436,7 +453,17 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     }
     const double fl = 2.0 * g.M * (double)g.N * g.K;
     g.N = (g.N + 127) / 128 * 128;
-    const int r = dtype_bf16 ? launch_big<bf16>(g, s) : launch_big<float>(g, s);
+    // Default: 128 x 128 tile, 4 waves, 2-slot ring (64 KB LDS -> two workgroups per CU, so one
+    // workgroup's prologue / epilogue hides behind the other's main loop): fastest on this path's
+    // shapes (K = 1024 / 4096, M = 15470).  PNP_GEMM_VARIANT=1 selects the 256 x 128, 8-wave, 3-slot
+    // variant (better only for K >= 8192).
+    static const int variant = getenv("PNP_GEMM_VARIANT") ? atoi(getenv("PNP_GEMM_VARIANT")) : 0;
+    int r;
+    if (variant == 1) {
+        r = dtype_bf16 ? launch_big<bf16, 256, 128, 64, 64, 3>(g, s) : launch_big<float, 256, 128, 64, 64, 3>(g, s);
+    } else {
+        r = dtype_bf16 ? launch_big<bf16, 128, 128, 64, 64, 2>(g, s) : launch_big<float, 128, 128, 64, 64, 2>(g, s);
+    }
     if (timed) {
         (void)hipEventRecord(pf.ev1[pf.used], s);
         pf.used++;

@@ -403,18 +403,35 @@ __global__ void argmax_kernel(const float* __restrict__ q, const PostDesc* __res
     }
 }
 
-// confusion histogram: hist[n_class * gt + pred] += 1 for 0 <= gt < n_class  (PnP.py:1106-1112)
-__global__ void hist_kernel(const uint8_t* __restrict__ labels, const float* __restrict__ gt, const PostDesc* __restrict__ desc,
-                            const size_t* __restrict__ label_off, unsigned long long* __restrict__ hist, int n_class) {
+// confusion histogram: hist[n_class * gt + pred] += 1 for 0 <= gt < n_class  (PnP.py:1106-1112).
+// Counts are privatised per workgroup in LDS (integer adds: order-independent, exact) and flushed
+// with one global atomic per non-zero bin; n_class^2 > 8192 bins falls back to global atomics.
+__global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ labels, const float* __restrict__ gt,
+                                                   const PostDesc* __restrict__ desc, const size_t* __restrict__ label_off,
+                                                   unsigned long long* __restrict__ hist, int n_class) {
+    __shared__ unsigned int bins[8192];
     const int b = blockIdx.y;
     const PostDesc d = desc[b];
-    const int n = d.H * d.W;
+    const int n = d.H * d.W, nb = n_class * n_class;
+    const bool use_lds = nb <= 8192;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < nb; i += 256) bins[i] = 0;
+        __syncthreads();
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float g = gt[label_off[b] + i];
         if (g >= 0.f && g < (float)n_class) {
             const int gi = (int)g, pi = labels[label_off[b] + i];
-            if (pi < n_class) atomicAdd(&hist[(size_t)gi * n_class + pi], 1ULL);
+            if (pi < n_class) {
+                if (use_lds) atomicAdd(&bins[gi * n_class + pi], 1u);
+                else atomicAdd(&hist[(size_t)gi * n_class + pi], 1ULL);
+            }
         }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb; i += 256)
+            if (bins[i]) atomicAdd(&hist[i], (unsigned long long)bins[i]);
     }
 }
 
