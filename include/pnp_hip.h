@@ -150,6 +150,10 @@ int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms
 int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,
                 const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, int32_t gelu,
                 void* stream);
+/* Same with the compute-type (bf16 / fp32) output and epilogue mode (0 linear, 1 GELU) exposed. */
+int pnp_op_gemm_ex(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,
+                   const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, void* d_out_t,
+                   int32_t ldo_t, int32_t mode, void* stream);
 int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                      float* d_y, void* stream);
 int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream);

@@ -1181,6 +1181,15 @@ extern "C" int pnp_op_gemm(int32_t bf, const void* d_A, int32_t lda, const void*
     return gemm_nt(bf, g, (hipStream_t)stream);
 }
 
+extern "C" int pnp_op_gemm_ex(int32_t bf, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,
+                              int32_t K, const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo,
+                              void* d_out_t, int32_t ldo_t, int32_t mode, void* stream) {
+    GemmArgs g = G_(d_A, lda, d_B, ldb, M, N, K);
+    g.bias = d_bias; g.resid = d_resid; g.ldr = ldr; g.out_f32 = d_out_f32; g.ldo = ldo; g.out_t = d_out_t; g.ldo_t = ldo_t;
+    g.mode = mode ? GEMM_EPI_GELU : GEMM_EPI_LINEAR;
+    return gemm_nt(bf, g, (hipStream_t)stream);
+}
+
 extern "C" int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                                 float* d_y, void* stream) {
     return layernorm(0, d_x, d_w, d_b, eps, rows, D, d_y, nullptr, nullptr, nullptr, (hipStream_t)stream);

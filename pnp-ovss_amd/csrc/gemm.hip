@@ -57,10 +57,12 @@ __device__ __forceinline__ RowCtx row_ctx(const GemmArgs& g, int m) {
     return rc;
 }
 
+// preloaded: bias (and, in LINEAR mode, the residual) were already folded into the accumulator's
+// initial value, so the epilogue issues no loads.
 template <typename T>
-__device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, f32x4 v, int m, int n) {
+__device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, f32x4 v, int m, int n, bool preloaded = false) {
     const int orow = rc.orow;
-    if (g.bias) {
+    if (g.bias && !preloaded) {
         if (g.bias_on_rows) {
             v += rc.bias_row;
         } else {
@@ -77,7 +79,7 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, 
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] *= gelu_erf_grad(u[e]);
     }
-    if (rc.resid_row) {
+    if (rc.resid_row && !(preloaded && g.mode == GEMM_EPI_LINEAR)) {
         const f32x4 rv = *reinterpret_cast<const f32x4*>(rc.resid_row + n);
         v += rv;
     }
@@ -135,7 +137,6 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     constexpr int WN = BN / WTN, NWAVES = (BM / WTM) * WN;
-    constexpr int MFMA_PER_READ = (TM * TN) / (TM + TN);
     constexpr int A_DMA = BM / 8 / NWAVES, B_DMA = BN / 8 / NWAVES, NDMA = A_DMA + B_DMA;   // per wave per slab
     static_assert(BM % (8 * NWAVES) == 0 && BN % (8 * NWAVES) == 0, "tile rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,45 +151,63 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
     tile_coords<(BM >= 256 ? 4 : 8)>(blockIdx.x, nbm, nbn, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
 
-    // DMA assignment: wave w moves A rows [8*A_DMA*w, ..) and B rows [8*B_DMA*w, ..), 8 rows per DMA
-    const char* src[NDMA];
-    int dst[NDMA];
+    // DMA assignment: wave w moves A rows [8*A_DMA*w, ..) and B rows [8*B_DMA*w, ..), 8 rows per DMA.
+    // Per-lane sources are kept as 32-bit byte offsets from the (uniform) operand bases.
+    const char* Ab = reinterpret_cast<const char*>(g.A);
+    const char* Bb = reinterpret_cast<const char*>(g.B);
+    uint32_t soff[NDMA];
     {
-        const char* Ab = reinterpret_cast<const char*>(g.A);
-        const char* Bb = reinterpret_cast<const char*>(g.B);
-        const size_t lda_b = (size_t)g.lda * Elem<T>::kBytes, ldb_b = (size_t)g.ldb * Elem<T>::kBytes;
+        const uint32_t lda_b = (uint32_t)g.lda * Elem<T>::kBytes, ldb_b = (uint32_t)g.ldb * Elem<T>::kBytes;
         const int pc = lane & 7;
 #pragma unroll
         for (int i = 0; i < A_DMA; i++) {
             const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
             int gr = m0 + row;
             gr = gr < g.M ? gr : g.M - 1;
-            src[i] = Ab + (size_t)gr * lda_b + swz_chunk<ROWB>(row, pc) * 16;
-            dst[i] = (wave * A_DMA + i) * 8 * ROWB;                    // wave-uniform DMA base
+            soff[i] = (uint32_t)gr * lda_b + swz_chunk<ROWB>(row, pc) * 16;
         }
 #pragma unroll
         for (int i = 0; i < B_DMA; i++) {
             const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
             int gr = n0 + row;
             gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
-            src[A_DMA + i] = Bb + (size_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
-            dst[A_DMA + i] = BM * ROWB + (wave * B_DMA + i) * 8 * ROWB;
+            soff[A_DMA + i] = (uint32_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
         }
     }
     auto issue = [&](int kt) {
         char* stage = smem + (kt % NS) * STAGE;
-        const size_t koff = (size_t)kt * ROWB;
+        const uint32_t koff = (uint32_t)kt * ROWB;
 #pragma unroll
-        for (int i = 0; i < NDMA; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(stage + dst[i]), 16, 0, 0);
+        for (int i = 0; i < NDMA; i++) {
+            const char* base = i < A_DMA ? Ab : Bb;
+            const int d = i < A_DMA ? (wave * A_DMA + i) * 8 * ROWB : BM * ROWB + (wave * B_DMA + (i - A_DMA)) * 8 * ROWB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[i] + koff)),
+                                             (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
+        }
     };
 
+    // accumulators start at bias (+ residual in LINEAR mode): those loads fly during the DMA prologue
+    // and the epilogue becomes store-only
     f32x4 acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < TN; i++)
+    for (int j = 0; j < TM; j++) {
+        const int m = m0 + wm * WTM + j * 16 + r;
+        const bool mv = m < g.M;
+        const RowCtx rc = row_ctx(g, mv ? m : g.M - 1);
 #pragma unroll
-        for (int j = 0; j < TM; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TN; i++) {
+            const int n = n0 + wn * WTN + i * 16 + q * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (mv && n + 3 < g.Nvalid) {
+                if (g.bias) {
+                    if (g.bias_on_rows) v += rc.bias_row;
+                    else v = *reinterpret_cast<const f32x4*>(g.bias + n);
+                }
+                if (rc.resid_row && g.mode == GEMM_EPI_LINEAR) v += *reinterpret_cast<const f32x4*>(rc.resid_row + n);
+            }
+            acc[i][j] = v;
+        }
+    }
 
     const int nk = g.K / BK;
     constexpr int KSTEPS = BK / 32;
@@ -212,6 +231,24 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
         // whose operands are already in registers.  After the barrier of iteration kt slab kt lives
         // entirely in registers, so its ring slot is refilled with slab kt+NS: slabs kt+1 (landed)
         // .. kt+NS-1 (in flight) occupy the other slots.
+        // A fragment j is dead after the TN MFMAs of its row, so the next step's A fragment j is read
+        // right behind them (same registers); only the TN B fragments are double-buffered.
+        auto step = [&](Frag<T>* fa_cur, const Frag<T>* fb_cur, Frag<T>* fb_nxt, int kt_n, int ks_n, bool have_next) {
+            const char* cA = smem + (kt_n % NS) * STAGE;
+            const char* cB = cA + BM * ROWB;
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+#pragma unroll
+                for (int i = 0; i < TN; i++) mma16(acc[i][j], fb_cur[i], fa_cur[j]);
+                if (have_next) {
+                    lds_frag<ROWB>(fa_cur[j], cA, wm * WTM + j * 16 + r, ks_n, q);
+                    if (j < TN) lds_frag<ROWB>(fb_nxt[j], cB, wn * WTN + j * 16 + r, ks_n, q);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TN, 0);                  // TN MFMAs
+                if (j < TN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // then this row's refill reads
+                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
 #pragma unroll
         for (int i = 0; i < NS; i++)
             if (i < nk) issue(i);
@@ -220,31 +257,19 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
         else if (NS > 2 && nk == NS - 1) PNP_WAIT_VM((NS > 2 ? NS - 2 : 0) * NDMA);
         else PNP_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
-        Frag<T> fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-        read_frags(fa0, fb0, 0, 0);
+        Frag<T> fa[TM], fb0[TN], fb1[TN];
+        read_frags(fa, fb0, 0, 0);
         for (int kt = 0; kt < nk; kt++) {
-            read_frags(fa1, fb1, kt, 1);
-            mma_step(fa0, fb0);
-#pragma unroll
-            for (int x = 0; x < TM + TN; x++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER_READ, 0);   // MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               // 1 DS read
-            }
+            step(fa, fb0, fb1, kt, 1, true);                 // MFMAs of (kt, 0) || reads of (kt, 1)
             if (kt + 1 < nk) {
                 // own reads of slab kt are complete, slab kt+1 has landed (younger slabs stay in flight)
                 if (kt + NS - 1 < nk) PNP_WAIT_VM_LGKM((NS - 2) * NDMA);
                 else PNP_WAIT_VM_LGKM(0);
                 __builtin_amdgcn_s_barrier();
                 if (kt + NS < nk) issue(kt + NS);
-                read_frags(fa0, fb0, kt + 1, 0);
-                mma_step(fa1, fb1);
-#pragma unroll
-                for (int x = 0; x < TM + TN; x++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, MFMA_PER_READ, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
+                step(fa, fb1, fb0, kt + 1, 0, true);         // MFMAs of (kt, 1) || reads of (kt+1, 0)
             } else {
-                mma_step(fa1, fb1);
+                step(fa, fb1, fb0, kt, 0, false);
             }
         }
     } else {
@@ -277,7 +302,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
         for (int i = 0; i < TN; i++) {
             const int n = n0 + wn * WTN + i * 16 + q * 4;
             if (n >= g.Nvalid) continue;
-            store_frag<T>(g, rc, acc[i][j], m, n);
+            store_frag<T>(g, rc, acc[i][j], m, n, n + 3 < g.Nvalid);
         }
     }
 }
@@ -407,7 +432,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
         for (int i = 0; i < TN; i++) {
             const int n = n0 + wn * WTN + i * 16 + q * 4;
             if (n >= g.Nvalid) continue;
-            store_frag<T>(g, rc, acc[i][j], m, n);
+            store_frag<T>(g, rc, acc[i][j], m, n, n + 3 < g.Nvalid);
         }
     }
 }
@@ -461,6 +486,9 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     int r;
     if (variant == 1) {
         r = dtype_bf16 ? launch_big<bf16, 256, 128, 64, 64, 3>(g, s) : launch_big<float, 256, 128, 64, 64, 3>(g, s);
+    } else if (variant == 2 && dtype_bf16) {       // 256 x 256 tile, 8 waves (2 x 4) of 128 x 64, 2-slot ring
+        g.N = (g.Nvalid + 255) / 256 * 256;
+        r = launch_big<bf16, 256, 256, 128, 64, 2>(g, s);
     } else {
         r = dtype_bf16 ? launch_big<bf16, 128, 128, 64, 64, 2>(g, s) : launch_big<float, 128, 128, 64, 64, 2>(g, s);
     }
