@@ -71,8 +71,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    distributed = "RANK" in os.environ          # launched by torch.distributed.run (also for N = 1)
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -95,7 +97,7 @@ def main():
             w = synth.synth_tensor(n, shp, 0)
             flat[o:o + w.size].copy_(torch.from_numpy(w.reshape(-1)))
             o += w.size
-    if world > 1:
+    if distributed:
         dist.broadcast(flat, src=0)
     sd, o = {}, 0
     for n, shp in shapes.items():
@@ -131,7 +133,7 @@ def main():
         state["ln"] = e.postprocess(agg, THRESH, False, "blur+crf", 21, histn)
 
     def sync():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -146,7 +148,7 @@ def main():
     dt = time.perf_counter() - t0
     launches, flops, ms = e.profile_read()
     e.profile_enable(False)
-    if world > 1:
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -179,7 +181,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, 0, 1)
         print(json.dumps(out))
     e.close()
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -463,8 +463,12 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     const bool small = tiles128 < 192;
     if (small) {
+        // text side (M = B*L rows): 64 x 64 tiles, 4 waves of 32 x 32, 3-slot DMA ring -- the deep
+        // prefetch matters more than tile efficiency for these latency-bound launches
         g.N = (g.N + 63) / 64 * 64;
-        return dtype_bf16 ? launch_cfg<bf16, 64, 64>(g, s) : launch_cfg<float, 64, 64>(g, s);
+        static const int small_variant = getenv("PNP_GEMM_SMALL") ? atoi(getenv("PNP_GEMM_SMALL")) : 0;
+        if (small_variant == 1) return dtype_bf16 ? launch_cfg<bf16, 64, 64>(g, s) : launch_cfg<float, 64, 64>(g, s);
+        return dtype_bf16 ? launch_big<bf16, 64, 64, 32, 32, 3>(g, s) : launch_big<float, 64, 64, 32, 32, 3>(g, s);
     }
     GemmProfile& pf = gemm_profile();
     const bool timed = pf.on && pf.used < GemmProfile::kMax;

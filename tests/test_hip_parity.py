@@ -369,3 +369,70 @@ def test_full_size_properties_336():
     torch.cuda.synchronize()
     np.testing.assert_array_equal(labels2.cpu().numpy(), lab)
     e.close()
+
+
+# ------------------------------------------------------------------------------------------ end to end
+
+@pytest.mark.parametrize("fname", ["pipeline_voc.npz", "pipeline_psc.npz"])
+def test_end_to_end_f32_labels_vs_reference_run(fname):
+    """Whole path in fp32 mode (model -> drop loop -> merge -> threshold/upsample -> blur -> argmax ->
+    remap) against the label maps the REFERENCE ITSELF produced (save_img_union_attention, golden),
+    and with CRF against the oracle.  Only float near-ties may differ."""
+    g = _golden(fname)
+    cfg = _cfg(g)
+    data_type = str(g["data_type"])
+    cats = {int(k): v for k, v in json.loads(str(g["cats"])).items()}
+    nms = list(cats.values())
+    B = 3
+    rgb_in, imgs = synth.synth_images(B, cfg.img_size, seed=int(g["image_seed"]))
+    sizes = [tuple(int(v) for v in s) for s in g["sizes"]]
+    rng = np.random.default_rng(int(g["org_seed"]))
+    org = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    gpt = json.loads(str(g["gpt"]))
+    from pnp_ovss import host
+    tok = SynthTokenizer(cfg.vocab)
+    best, caps = [], []
+    for k in [str(s) for s in g["img_ids"]]:
+        b, names, cap = host.parse_gpt_classes(gpt[k], nms)
+        best.append(b)
+        caps.append(cap)
+    enc = tok(caps, padding="max_length", max_length=500)
+    ids, mask = enc.input_ids.numpy(), enc.attention_mask.numpy()
+    L = int(mask.sum(1).max())
+    e = _engine(cfg, int(g["weight_seed"]), False)
+    if not getattr(e, "_reserved", False):
+        e.post_reserve(4, 4 * 128 * 128, 128 * 128, 8, 0)
+        e._reserved = True
+    g0, agg, picks, _ = e.drop_loop(_dev(imgs), _dev(ids), _dev(mask), L, 9, 4)
+    plans, luts, bgs = [], [], []
+    for i in range(B):
+        pieces = host.caption_pieces(tok, ids[i])
+        bg = host.has_background(data_type, len(best[i]))
+        plans.append(host.merge_plan(pieces, len(best[i])))
+        luts.append(host.remap_lut(best[i], bg, len(best[i]) + int(bg)))
+        bgs.append(bg)
+    d_rgb = _dev(np.concatenate([r.reshape(-1) for r in org]))
+    e.post_prepare(sizes, plans, luts, bgs, rgb=d_rgb, gt=None, want_crf=True)
+    total = sum(h * w for h, w in sizes)
+    for name, src, scale01 in (("1drop", g0, True), ("ndrop", agg, False)):
+        for mode in ("blur", None):
+            labels = e.split_labels(e.postprocess(src, 0.15, scale01, mode))
+            torch.cuda.synchronize()
+            maps = [m.cpu().numpy() for m in e.post_maps("maps")]
+            bad = 0
+            for i in range(B):
+                ref = g[f"labels_{name}_{mode or 'none'}_{i}"]
+                diff = labels[i].cpu().numpy() != ref
+                if maps[i].shape[0] > 1:                           # a flip is legitimate only where the two best
+                    srt = np.sort(maps[i], axis=0)                 # channels agree to float rounding (proportional maps)
+                    diff &= ~((srt[-1] - srt[-2]) <= 1e-4 * np.abs(srt[-1]))
+                bad += int(diff.sum())
+            assert bad == 0, (name, mode, bad)
+    # blur + CRF: device path vs the oracle run on the same inputs end to end
+    W = synth.synth_state_dict(cfg, int(g["weight_seed"]))
+    pieces_o = [host.caption_pieces(tok, ids[i]) for i in range(B)]
+    l1, ln, _ = OP.segment_batch(W, cfg, imgs, ids, mask, pieces_o, best, org, sizes, data_type=data_type, mode="blur+crf")
+    got = e.split_labels(e.postprocess(agg, 0.15, False, "blur+crf"))
+    torch.cuda.synchronize()
+    bad = sum(int((got[i].cpu().numpy().astype(np.float32) != ln[i]).sum()) for i in range(B))
+    assert bad <= 0.003 * total, bad
