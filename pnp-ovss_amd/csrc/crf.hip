@@ -385,82 +385,88 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
                                                          const float* __restrict__ vg, const float* __restrict__ vb,
                                                          const float* __restrict__ norm_g, const float* __restrict__ norm_b,
                                                          const float* __restrict__ unary, float* __restrict__ Q, float w_g,
-                                                         float w_b, float alpha_g, float alpha_b, int pairwise, int img0) {
+                                                         float w_b, float alpha_g, float alpha_b, int pairwise, int img0,
+                                                         int nimg) {
     extern __shared__ __attribute__((aligned(16))) float tile[];        // [CRF_TP][Kp + 1]
-    const int b = img0 + blockIdx.y;
-    const PostDesc im = imgs[b];
-    const int n = im.H * im.W;
-    const int p0 = blockIdx.x * CRF_TP;
-    if (p0 >= n) return;
-    const int K = im.K, Kp = im.Kp, K4 = Kp >> 2, ldt = Kp + 1;
+    // XCD-affine sweep like the splat / blur kernels: the slice gathers of an image hit the value rows
+    // its XCD has just blurred
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const int tid = threadIdx.x;
-    const f32x4* U4 = reinterpret_cast<const f32x4*>(unary + im.qoff);
-    f32x4* Q4 = reinterpret_cast<f32x4*>(Q + im.qoff);
-    const int lo_g = pairwise ? Lg.idbase[b] : 0, lo_b = pairwise ? Lb.idbase[b] : 0;
-    const f32x4* G4 = reinterpret_cast<const f32x4*>(vg + im.voff[0]);
-    const f32x4* B4 = reinterpret_cast<const f32x4*>(vb + im.voff[1]);
-    const int np = (n - p0) < CRF_TP ? (n - p0) : CRF_TP;
-    for (int item = tid; item < np * K4; item += 256) {
-        const int pl = item / K4, c = item - pl * K4;
-        const int pix = p0 + pl;
-        const f32x4 u = U4[(size_t)pix * K4 + c];
-        f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
-        if (pairwise) {
-            const size_t gp = (size_t)im.pix0 + pix;
-            {
-                f32x4 out = {0.f, 0.f, 0.f, 0.f};
-                const size_t pv0 = gp * 3;
+    for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
+        const PostDesc im = imgs[b];
+        const int n = im.H * im.W;
+        const int K = im.K, Kp = im.Kp, K4 = Kp >> 2, ldt = Kp + 1;
+        const f32x4* U4 = reinterpret_cast<const f32x4*>(unary + im.qoff);
+        f32x4* Q4 = reinterpret_cast<f32x4*>(Q + im.qoff);
+        const int lo_g = pairwise ? Lg.idbase[b] : 0, lo_b = pairwise ? Lb.idbase[b] : 0;
+        const f32x4* G4 = reinterpret_cast<const f32x4*>(vg + im.voff[0]);
+        const f32x4* B4 = reinterpret_cast<const f32x4*>(vb + im.voff[1]);
+        for (int p0 = slot * CRF_TP; p0 < n; p0 += bpx * CRF_TP) {
+            const int np = (n - p0) < CRF_TP ? (n - p0) : CRF_TP;
+            for (int item = tid; item < np * K4; item += 256) {
+                const int pl = item / K4, c = item - pl * K4;
+                const int pix = p0 + pl;
+                const f32x4 u = U4[(size_t)pix * K4 + c];
+                f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
+                if (pairwise) {
+                    const size_t gp = (size_t)im.pix0 + pix;
+                    {
+                        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                        const size_t pv0 = gp * 3;
 #pragma unroll
-                for (int v = 0; v < 3; v++) {
-                    const f32x4 val = G4[(size_t)(Lg.offset[pv0 + v] - lo_g) * K4 + c];
-                    const float wv = Lg.bary[pv0 + v];
+                        for (int v = 0; v < 3; v++) {
+                            const f32x4 val = G4[(size_t)(Lg.offset[pv0 + v] - lo_g) * K4 + c];
+                            const float wv = Lg.bary[pv0 + v];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_g));
+                            for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_g));
+                        }
+                        const float nr = norm_g[gp];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_g, __fmul_rn(out[i], nr)));
+                    }
+                    {
+                        f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                        const size_t pv0 = gp * 6;
+#pragma unroll
+                        for (int v = 0; v < 6; v++) {
+                            const f32x4 val = B4[(size_t)(Lb.offset[pv0 + v] - lo_b) * K4 + c];
+                            const float wv = Lb.bary[pv0 + v];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_b));
+                        }
+                        const float nr = norm_b[gp];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_b, __fmul_rn(out[i], nr)));
+                    }
                 }
-                const float nr = norm_g[gp];
 #pragma unroll
-                for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_g, __fmul_rn(out[i], nr)));
+                for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
             }
-            {
-                f32x4 out = {0.f, 0.f, 0.f, 0.f};
-                const size_t pv0 = gp * 6;
-#pragma unroll
-                for (int v = 0; v < 6; v++) {
-                    const f32x4 val = B4[(size_t)(Lb.offset[pv0 + v] - lo_b) * K4 + c];
-                    const float wv = Lb.bary[pv0 + v];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_b));
+            __syncthreads();
+            if (tid < np) {
+                float* row = tile + tid * ldt;
+                float m = row[0];
+                for (int k = 1; k < K; k++) {
+                    const float v = row[k];
+                    if (v > m || v != v) m = v;
                 }
-                const float nr = norm_b[gp];
-#pragma unroll
-                for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_b, __fmul_rn(out[i], nr)));
+                float s = 0.f;
+                for (int k = 0; k < K; k++) {
+                    const float e = pnp_expf(__fsub_rn(row[k], m));
+                    row[k] = e;
+                    s = __fadd_rn(s, e);
+                }
+                for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
+                for (int k = K; k < Kp; k++) row[k] = 0.f;
             }
+            __syncthreads();
+            for (int item = tid; item < np * K4; item += 256) {
+                const int pl = item / K4, c = item - pl * K4;
+                const float* r = tile + pl * ldt + 4 * c;
+                Q4[(size_t)(p0 + pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
+            }
+            __syncthreads();
         }
-#pragma unroll
-        for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
-    }
-    __syncthreads();
-    if (tid < np) {
-        float* row = tile + tid * ldt;
-        float m = row[0];
-        for (int k = 1; k < K; k++) {
-            const float v = row[k];
-            if (v > m || v != v) m = v;
-        }
-        float s = 0.f;
-        for (int k = 0; k < K; k++) {
-            const float e = pnp_expf(__fsub_rn(row[k], m));
-            row[k] = e;
-            s = __fadd_rn(s, e);
-        }
-        for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
-        for (int k = K; k < Kp; k++) row[k] = 0.f;
-    }
-    __syncthreads();
-    for (int item = tid; item < np * K4; item += 256) {
-        const int pl = item / K4, c = item - pl * K4;
-        const float* r = tile + pl * ldt + 4 * c;
-        Q4[(size_t)(p0 + pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
     }
 }
 
@@ -564,8 +570,9 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
                                 (int)smem) != hipSuccess)
             return PNP_ERR_HIP;
     }
-    hipLaunchKernelGGL(crf_update_kernel, dim3((max_pixels + CRF_TP - 1) / CRF_TP, nimg), dim3(256), smem, s, Lg, Lb, d_imgs,
-                       vg, vb, norm_g, norm_b, unary, Q, w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0);
+    (void)max_pixels;
+    hipLaunchKernelGGL(crf_update_kernel, dim3(8 * 256), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
+                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg);
     return ok();
 }
 

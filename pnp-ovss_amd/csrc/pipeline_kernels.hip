@@ -276,49 +276,52 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return m >= n ? period - 1 - m : m;
 }
 
-// Each thread owns up to 8 outputs of the tile and walks the taps once for all of them (8
-// independent fp64 chains hide the dadd latency at one wave per SIMD).  Output (r, c) of the tile
-// reads xs[r * row_stride + c + base + (+-j) * tap_stride].
-__device__ __forceinline__ void blur_tile_outputs(const double* __restrict__ xs, const double* __restrict__ wl, int radius,
-                                                  int row_stride, int base, int tap_stride, int TH, int TW, int y0, int x0,
-                                                  int H, int W, float* __restrict__ dst, int tid) {
-    constexpr int OPT = 8;
-    const int nout = TH * TW;
-    const double* ctr[OPT];
-    double acc[OPT];
+// Sliding-window evaluation: a thread owns R = 8 CONSECUTIVE outputs along the filtered axis.  For
+// tap distance j the eight left samples x[o_i - j] and the eight right samples x[o_i + j] form two
+// register windows that shift by one element when j decreases, so each tap costs two LDS reads (plus
+// the broadcast weight) for eight outputs instead of sixteen.  The j loop is unrolled by 8 so the
+// window rotation is compile-time register renaming.  Per output the sum is still
+// x[o]*w[0] + sum_{j=r..1} (x[o-j] + x[o+j]) * w[j] in scipy's order, in fp64.
+//   ctr: LDS address of output 0 of the thread, S: element stride along the filtered axis.
+__device__ __forceinline__ void blur_window8(const double* __restrict__ ctr, int S, const double* __restrict__ wl, int radius,
+                                             double* __restrict__ acc) {
+    constexpr int R = 8;
+    double lo[R], hi[R];
 #pragma unroll
-    for (int i = 0; i < OPT; i++) {
-        int o = tid + 256 * i;
-        o = o < nout ? o : nout - 1;
-        const int r = o / TW, c = o - r * TW;
-        ctr[i] = xs + (size_t)r * row_stride + c + base;
-        acc[i] = __dmul_rn(ctr[i][0], wl[0]);
+    for (int i = 0; i < R; i++) {
+        acc[i] = __dmul_rn(ctr[i * S], wl[0]);
+        lo[i] = ctr[(i - radius) * S];
+        hi[i] = ctr[(i + radius) * S];
     }
-    for (int j = radius; j >= 1; j--) {
-        const double wj = wl[j];
-        const int d = j * tap_stride;
+    for (int j = radius; j >= 1; j -= R) {
 #pragma unroll
-        for (int i = 0; i < OPT; i++) acc[i] = __dadd_rn(acc[i], __dmul_rn(__dadd_rn(ctr[i][-d], ctr[i][d]), wj));
-    }
+        for (int jj = 0; jj < R; jj++) {
+            const int jc = j - jj;                      // current tap distance (may run past 1: predicated)
+            if (jc >= 1) {
+                const double wj = wl[jc];
 #pragma unroll
-    for (int i = 0; i < OPT; i++) {
-        const int o = tid + 256 * i;
-        if (o >= nout) continue;
-        const int r = o / TW, c = o - r * TW;
-        if (y0 + r < H && x0 + c < W) dst[(size_t)(y0 + r) * W + x0 + c] = (float)acc[i];
+                for (int i = 0; i < R; i++)             // logical window slot i lives in lo[(i + jj) % R], hi[(i - jj) & 7]
+                    acc[i] = __dadd_rn(acc[i], __dmul_rn(__dadd_rn(lo[(i + jj) % R], hi[(i - jj + R) % R]), wj));
+                // shift: lo gains x[o_{R-1} - (jc-1)], hi gains x[o_0 + (jc-1)]
+                lo[jj % R] = ctr[(R - jc) * S];
+                hi[(R - 1 - jj) % R] = ctr[(jc - 1) * S];
+            }
+        }
     }
 }
 
-// LDS-tiled: a workgroup stages its tile + halo once as fp64 (the conversion scipy's line buffer
-// does) and every tap is a conflict-free ds_read_b64; the per-output sum keeps scipy's order.
-// Tile = TH rows x TW cols of outputs; halo of `radius` along the filtered axis.
+// LDS-tiled separable pass: a workgroup stages its 32 x 64 output tile + halo once as fp64 (the
+// conversion scipy's line buffer does); 256 threads x 8 consecutive outputs each.
+//   axis 0 (vertical):   xs[(32 + 2r)][64],        thread = (column c, row group of 8)
+//   axis 1 (horizontal): xs[32][colsP], colsP = 64 + 2r rounded up to odd (bank-conflict-free row stride),
+//                        thread = (row, column group of 8)
 __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const PostDesc* __restrict__ desc, const double* __restrict__ wts,
-                                                        const int32_t* __restrict__ wt_off, int axis, int TH, int TW,
-                                                        int max_radius) {
+                                                        const int32_t* __restrict__ wt_off, int axis, int max_radius) {
+    constexpr int TH = 32, TW = 64;
     extern __shared__ __attribute__((aligned(16))) double tile[];
     double* wl = tile;                               // [max_radius + 1] taps
-    double* xs = tile + (max_radius + 1);            // staged samples
+    double* xs = tile + (max_radius + 2);            // staged samples
     const int b = blockIdx.z, k = blockIdx.y;
     const PostDesc d = desc[b];
     if (k >= d.K) return;
@@ -330,10 +333,12 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
     float* dst = out + d.off + (size_t)k * H * W;
     const int tid = threadIdx.x;
     for (int j = tid; j <= radius; j += 256) wl[j] = w[j];
+    const int colsP = (TW + 2 * radius) | 1;
     for (int tl = blockIdx.x; tl < tiles_x * tiles_y; tl += gridDim.x) {
         const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
         __syncthreads();
+        double acc[8];
         if (axis == 0) {
             const int rows = TH + 2 * radius;            // xs[rows][TW]
             for (int i = tid; i < rows * TW; i += 256) {
@@ -342,16 +347,33 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
                 xs[i] = (double)src[(size_t)reflect_idx(y0 - radius + r, H) * W + x];
             }
             __syncthreads();
-            blur_tile_outputs(xs, wl, radius, TW, radius * TW, TW, TH, TW, y0, x0, H, W, dst, tid);
+            const int c = tid & 63, rg = tid >> 6;
+            blur_window8(xs + (size_t)(rg * 8 + radius) * TW + c, TW, wl, radius, acc);
+            if (x0 + c < W) {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (y0 + rg * 8 + i < H) dst[(size_t)(y0 + rg * 8 + i) * W + x0 + c] = (float)acc[i];
+            }
         } else {
-            const int cols = TW + 2 * radius;            // xs[TH][cols]
-            for (int i = tid; i < TH * cols; i += 256) {
-                const int r = i / cols, c = i - r * cols;
+            for (int i = tid; i < TH * colsP; i += 256) {
+                const int r = i / colsP, c = i - r * colsP;
                 const int y = y0 + r < H ? y0 + r : H - 1;
                 xs[i] = (double)src[(size_t)y * W + reflect_idx(x0 - radius + c, W)];
             }
             __syncthreads();
-            blur_tile_outputs(xs, wl, radius, cols, radius, 1, TH, TW, y0, x0, H, W, dst, tid);
+            const int rr = tid & 31, cg = tid >> 5;
+            blur_window8(xs + (size_t)rr * colsP + radius + cg * 8, 1, wl, radius, acc);
+            if (y0 + rr < H) {
+                float* o = dst + (size_t)(y0 + rr) * W + x0 + cg * 8;
+                if (x0 + cg * 8 + 7 < W && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                    reinterpret_cast<f32x4*>(o)[0] = f32x4{(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+                    reinterpret_cast<f32x4*>(o)[1] = f32x4{(float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]};
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (x0 + cg * 8 + i < W) o[i] = (float)acc[i];
+                }
+            }
         }
     }
 }
@@ -490,31 +512,20 @@ int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipS
 
 int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
               int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s) {
-    // tile 32 x 64 outputs (2048 per workgroup); shrink the unfiltered extent when the halo is long
-    int TH = 32, TW = 64;
-    auto lds = [&](int th, int tw, int axis) {
-        return (size_t)(max_radius + 1 + (axis == 0 ? (th + 2 * max_radius) * tw : th * (tw + 2 * max_radius))) * sizeof(double);
-    };
-    int th0 = 32, tw0 = 64;                       // vertical pass: halo multiplies TW
-    while (lds(th0, tw0, 0) > 150 * 1024 && tw0 > 16) tw0 >>= 1;
-    int th1 = 32, tw1 = 64;                       // horizontal pass: halo multiplies TH
-    while (lds(th1, tw1, 1) > 150 * 1024 && th1 > 8) th1 >>= 1;
-    if (lds(th0, tw0, 0) > 160 * 1024 || lds(th1, tw1, 1) > 160 * 1024) return PNP_ERR_ARG;
-    (void)TH; (void)TW;
-    static size_t attr_bytes = 0;
-    const size_t need = lds(th0, tw0, 0) > lds(th1, tw1, 1) ? lds(th0, tw0, 0) : lds(th1, tw1, 1);
-    if (need > attr_bytes) {
+    const size_t lds0 = (size_t)(max_radius + 2 + (32 + 2 * max_radius) * 64) * sizeof(double);
+    const size_t lds1 = (size_t)(max_radius + 2 + 32 * ((64 + 2 * max_radius) | 1)) * sizeof(double);
+    const size_t need = lds0 > lds1 ? lds0 : lds1;
+    if (need > 160 * 1024) return PNP_ERR_ARG;            // radius <= 143 (images up to ~715 px on the long side)
+    static bool attr_set = false;
+    if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(blur_axis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(160 * 1024)) != hipSuccess)
+                                160 * 1024) != hipSuccess)
             return PNP_ERR_HIP;
-        attr_bytes = 160 * 1024;
+        attr_set = true;
     }
-    const int t0 = ((maxW + tw0 - 1) / tw0) * ((maxH + th0 - 1) / th0);
-    const int t1 = ((maxW + tw1 - 1) / tw1) * ((maxH + th1 - 1) / th1);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(t0, Kmax, B), dim3(256), lds(th0, tw0, 0), s, in, tmp, desc, wts, wt_off, 0, th0, tw0,
-                       max_radius);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(t1, Kmax, B), dim3(256), lds(th1, tw1, 1), s, tmp, out, desc, wts, wt_off, 1, th1, tw1,
-                       max_radius);
+    const int tiles = ((maxW + 63) / 64) * ((maxH + 31) / 32);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles, Kmax, B), dim3(256), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles, Kmax, B), dim3(256), lds1, s, tmp, out, desc, wts, wt_off, 1, max_radius);
     return ok();
 }
 
