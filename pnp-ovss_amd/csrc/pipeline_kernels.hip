@@ -281,17 +281,18 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 // register windows that shift by one element when j decreases, so each tap costs two LDS reads (plus
 // the broadcast weight) for eight outputs instead of sixteen.  The j loop is unrolled by 8 so the
 // window rotation is compile-time register renaming.  Per output the sum is still
-// x[o]*w[0] + sum_{j=r..1} (x[o-j] + x[o+j]) * w[j] in scipy's order, in fp64.
+// x[o]*w[0] + sum_{j=r..1} (x[o-j] + x[o+j]) * w[j] in scipy's order, in fp64 (samples are staged
+// as fp32 -- their storage type -- and widened on the way into the window, which is exact).
 //   ctr: LDS address of output 0 of the thread, S: element stride along the filtered axis.
-__device__ __forceinline__ void blur_window8(const double* __restrict__ ctr, int S, const double* __restrict__ wl, int radius,
+__device__ __forceinline__ void blur_window8(const float* __restrict__ ctr, int S, const double* __restrict__ wl, int radius,
                                              double* __restrict__ acc) {
     constexpr int R = 8;
     double lo[R], hi[R];
 #pragma unroll
     for (int i = 0; i < R; i++) {
-        acc[i] = __dmul_rn(ctr[i * S], wl[0]);
-        lo[i] = ctr[(i - radius) * S];
-        hi[i] = ctr[(i + radius) * S];
+        acc[i] = __dmul_rn((double)ctr[i * S], wl[0]);
+        lo[i] = (double)ctr[(i - radius) * S];
+        hi[i] = (double)ctr[(i + radius) * S];
     }
     for (int j = radius; j >= 1; j -= R) {
 #pragma unroll
@@ -303,25 +304,33 @@ __device__ __forceinline__ void blur_window8(const double* __restrict__ ctr, int
                 for (int i = 0; i < R; i++)             // logical window slot i lives in lo[(i + jj) % R], hi[(i - jj) & 7]
                     acc[i] = __dadd_rn(acc[i], __dmul_rn(__dadd_rn(lo[(i + jj) % R], hi[(i - jj + R) % R]), wj));
                 // shift: lo gains x[o_{R-1} - (jc-1)], hi gains x[o_0 + (jc-1)]
-                lo[jj % R] = ctr[(R - jc) * S];
-                hi[(R - 1 - jj) % R] = ctr[(jc - 1) * S];
+                lo[jj % R] = (double)ctr[(R - jc) * S];
+                hi[(R - 1 - jj) % R] = (double)ctr[(jc - 1) * S];
             }
         }
     }
 }
 
-// LDS-tiled separable pass: a workgroup stages its 32 x 64 output tile + halo once as fp64 (the
-// conversion scipy's line buffer does); 256 threads x 8 consecutive outputs each.
+// half-sample symmetric reflection; the branch-free form covers |overshoot| < n (always true here
+// unless the image is smaller than the kernel radius)
+__device__ __forceinline__ int reflect_fast(int i, int n) {
+    if (i >= 0 && i < n) return i;
+    const int m = i < 0 ? -i - 1 : 2 * n - 1 - i;
+    return (m >= 0 && m < n) ? m : reflect_idx(i, n);
+}
+
+// LDS-tiled separable pass: a workgroup stages its 32 x 64 output tile + halo once; 256 threads x 8
+// consecutive outputs each.
 //   axis 0 (vertical):   xs[(32 + 2r)][64],        thread = (column c, row group of 8)
-//   axis 1 (horizontal): xs[32][colsP], colsP = 64 + 2r rounded up to odd (bank-conflict-free row stride),
+//   axis 1 (horizontal): xs[32][colsP], colsP = 64 + 2r rounded up to odd (conflict-free row stride),
 //                        thread = (row, column group of 8)
 __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const PostDesc* __restrict__ desc, const double* __restrict__ wts,
                                                         const int32_t* __restrict__ wt_off, int axis, int max_radius) {
     constexpr int TH = 32, TW = 64;
     extern __shared__ __attribute__((aligned(16))) double tile[];
-    double* wl = tile;                               // [max_radius + 1] taps
-    double* xs = tile + (max_radius + 2);            // staged samples
+    double* wl = tile;                                                   // [max_radius + 1] taps
+    float* xs = reinterpret_cast<float*>(tile + (max_radius + 2));       // staged samples
     const int b = blockIdx.z, k = blockIdx.y;
     const PostDesc d = desc[b];
     if (k >= d.K) return;
@@ -341,13 +350,11 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
         double acc[8];
         if (axis == 0) {
             const int rows = TH + 2 * radius;            // xs[rows][TW]
-            for (int i = tid; i < rows * TW; i += 256) {
-                const int r = i / TW, c = i - r * TW;
-                const int x = x0 + c < W ? x0 + c : W - 1;
-                xs[i] = (double)src[(size_t)reflect_idx(y0 - radius + r, H) * W + x];
-            }
+            const int c = tid & 63;
+            const int x = x0 + c < W ? x0 + c : W - 1;
+            for (int r = tid >> 6; r < rows; r += 4) xs[r * TW + c] = src[(size_t)reflect_fast(y0 - radius + r, H) * W + x];
             __syncthreads();
-            const int c = tid & 63, rg = tid >> 6;
+            const int rg = tid >> 6;
             blur_window8(xs + (size_t)(rg * 8 + radius) * TW + c, TW, wl, radius, acc);
             if (x0 + c < W) {
 #pragma unroll
@@ -355,10 +362,10 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
                     if (y0 + rg * 8 + i < H) dst[(size_t)(y0 + rg * 8 + i) * W + x0 + c] = (float)acc[i];
             }
         } else {
-            for (int i = tid; i < TH * colsP; i += 256) {
-                const int r = i / colsP, c = i - r * colsP;
+            for (int r = 0; r < TH; r++) {
                 const int y = y0 + r < H ? y0 + r : H - 1;
-                xs[i] = (double)src[(size_t)y * W + reflect_idx(x0 - radius + c, W)];
+                const float* srow = src + (size_t)y * W;
+                for (int c = tid; c < colsP; c += 256) xs[r * colsP + c] = srow[reflect_fast(x0 - radius + c, W)];
             }
             __syncthreads();
             const int rr = tid & 31, cg = tid >> 5;
@@ -512,10 +519,10 @@ int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipS
 
 int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
               int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s) {
-    const size_t lds0 = (size_t)(max_radius + 2 + (32 + 2 * max_radius) * 64) * sizeof(double);
-    const size_t lds1 = (size_t)(max_radius + 2 + 32 * ((64 + 2 * max_radius) | 1)) * sizeof(double);
+    const size_t lds0 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)(32 + 2 * max_radius) * 64 * sizeof(float);
+    const size_t lds1 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)32 * ((64 + 2 * max_radius) | 1) * sizeof(float);
     const size_t need = lds0 > lds1 ? lds0 : lds1;
-    if (need > 160 * 1024) return PNP_ERR_ARG;            // radius <= 143 (images up to ~715 px on the long side)
+    if (need > 160 * 1024) return PNP_ERR_ARG;            // radius <= ~300 (images up to ~1500 px on the long side)
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(blur_axis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
