@@ -24,6 +24,7 @@ struct GemmArgs {
     int ld_aux = 0;
     int row_div = 0;               // >0: patch rows -> token rows b*(row_div+1)+1+p, resid = pos_embed
     int col_div = 0, col_pad = 0;  // >0: output column n -> (n / col_div) * col_pad + n % col_div
+    int ablate = 0;                // timing experiments only (PNP_GEMM_ABLATE): 1 = no steady-state DMA, 2 = no MFMA
 };
 
 int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s);

@@ -130,7 +130,7 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, 
 #define PNP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // BM x BN block tile, (BM/WTM) x (BN/WTN) waves of WTM x WTN, NS-slot LDS ring.
-template <typename T, int BM, int BN, int WTM, int WTN, int NS>
+template <typename T, int BM, int BN, int WTM, int WTN, int NS, bool PIPE = true>
 __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kernel(const GemmArgs g) {
     constexpr int ROWB = 128;
     constexpr int BK = ROWB / Elem<T>::kBytes;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
         }
     }
     auto issue = [&](int kt) {
+        if (g.ablate == 1 && kt >= NS) return;           // timing ablation: no steady-state DMA
         char* stage = smem + (kt % NS) * STAGE;
         const uint32_t koff = (uint32_t)kt * ROWB;
 #pragma unroll
@@ -225,7 +226,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
 #pragma unroll
             for (int j = 0; j < TM; j++) mma16(acc[i][j], fb[i], fa[j]);
     };
-    if constexpr (KSTEPS == 2) {
+    if constexpr (KSTEPS == 2 && PIPE) {
         // Pipeline (bf16): every MFMA cluster overlaps the fragment reads of the NEXT k-step, and the
         // slab hand-over (counted vmcnt + one s_barrier + next DMA issue) sits between two clusters
         // whose operands are already in registers.  After the barrier of iteration kt slab kt lives
@@ -238,8 +239,13 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
             const char* cB = cA + BM * ROWB;
 #pragma unroll
             for (int j = 0; j < TM; j++) {
+                if (g.ablate != 2) {
 #pragma unroll
-                for (int i = 0; i < TN; i++) mma16(acc[i][j], fb_cur[i], fa_cur[j]);
+                    for (int i = 0; i < TN; i++) mma16(acc[i][j], fb_cur[i], fa_cur[j]);
+                } else {                                     // timing ablation: no MFMA, operands kept alive
+#pragma unroll
+                    for (int i = 0; i < TN; i++) asm volatile("" ::"v"(fb_cur[i].v), "v"(fa_cur[j].v));
+                }
                 if (have_next) {
                     lds_frag<ROWB>(fa_cur[j], cA, wm * WTM + j * 16 + r, ks_n, q);
                     if (j < TN) lds_frag<ROWB>(fb_nxt[j], cB, wn * WTN + j * 16 + r, ks_n, q);
@@ -273,7 +279,8 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
             }
         }
     } else {
-        // fp32 parity mode (one k-step per slab): simple ring, two slabs in flight at most
+        // simple ring (fp32 parity mode: one k-step per slab; large-tile bf16 variant: fragments are
+        // not double-buffered, the co-resident wave of the SIMD covers the LDS latency)
         issue(0);
         if (nk > 1 && NS > 2) issue(1);
         for (int kt = 0; kt < nk; kt++) {
@@ -285,9 +292,14 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
             } else if (kt + 1 < nk) {
                 issue(kt + 1);
             }
-            Frag<T> fa[TM], fb[TN];
-            read_frags(fa, fb, kt, 0);
-            mma_step(fa, fb);
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                Frag<T> fa[TM], fb[TN];
+                read_frags(fa, fb, kt, ks);
+                __builtin_amdgcn_s_setprio(1);
+                mma_step(fa, fb);
+                __builtin_amdgcn_s_setprio(0);
+            }
             if (NS == 2) {                     // the single spare slot is refilled next iteration: finish reading first
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
@@ -307,18 +319,18 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
     }
 }
 
-template <typename T, int BM, int BN, int WTM, int WTN, int NS>
+template <typename T, int BM, int BN, int WTM, int WTN, int NS, bool PIPE = true>
 static int launch_big(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const size_t smem = (size_t)NS * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return PNP_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS>), dim3(nbm * nbn), dim3((BM / WTM) * (BN / WTN) * 64), smem, s, g);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>), dim3(nbm * nbn), dim3((BM / WTM) * (BN / WTN) * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
@@ -482,17 +494,24 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     }
     const double fl = 2.0 * g.M * (double)g.N * g.K;
     g.N = (g.N + 127) / 128 * 128;
-    // Default: 128 x 128 tile, 4 waves, 2-slot ring (64 KB LDS -> two workgroups per CU, so one
-    // workgroup's prologue / epilogue hides behind the other's main loop): fastest on this path's
-    // shapes (K = 1024 / 4096, M = 15470).  PNP_GEMM_VARIANT=1 selects the 256 x 128, 8-wave, 3-slot
-    // variant (better only for K >= 8192).
+    // The kernel is bound by what one CU can pull out of L2 / Infinity Cache (~40 GB/s measured), so
+    // the tile is chosen for arithmetic intensity against fixed per-workgroup cost:
+    //   K >= 2048 : 256 x 256 tile, 8 waves of 128 x 64, 2-slot ring (half the operand bytes per FLOP;
+    //               ~980 TFLOP/s on the fc2 shape)
+    //   otherwise : 128 x 128 tile, 4 waves of 64 x 64, 2-slot ring, software-pipelined fragments
+    //               (64 KB LDS -> two workgroups per CU, so one's prologue / epilogue hides behind the
+    //               other's main loop; best for the 16-slab K = 1024 shapes)
+    // PNP_GEMM_VARIANT=1 / 2 / 3 force 256x128 / 256x256 / 128x128 (experiments).
     static const int variant = getenv("PNP_GEMM_VARIANT") ? atoi(getenv("PNP_GEMM_VARIANT")) : 0;
+    static const int ablate = getenv("PNP_GEMM_ABLATE") ? atoi(getenv("PNP_GEMM_ABLATE")) : 0;
+    g.ablate = ablate;
     int r;
+    const bool big_k = g.K >= 2048 && g.Nvalid >= 512;
     if (variant == 1) {
         r = dtype_bf16 ? launch_big<bf16, 256, 128, 64, 64, 3>(g, s) : launch_big<float, 256, 128, 64, 64, 3>(g, s);
-    } else if (variant == 2 && dtype_bf16) {       // 256 x 256 tile, 8 waves (2 x 4) of 128 x 64, 2-slot ring
+    } else if (dtype_bf16 && (variant == 2 || (variant == 0 && big_k))) {
         g.N = (g.Nvalid + 255) / 256 * 256;
-        r = launch_big<bf16, 256, 256, 128, 64, 2>(g, s);
+        r = launch_big<bf16, 256, 256, 128, 64, 2, false>(g, s);
     } else {
         r = dtype_bf16 ? launch_big<bf16, 128, 128, 64, 64, 2>(g, s) : launch_big<float, 128, 128, 64, 64, 2>(g, s);
     }
