@@ -252,7 +252,7 @@ __global__ void crf_splat1_kernel(const CrfLattice L, const PostDesc* __restrict
     const int lo = L.idbase[b], hi = L.idbase[b + 1];
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < hi - lo; t += gridDim.x * blockDim.x) {
         const int id = lo + t;
-        const int e0 = L.seg_start[id], e1 = L.seg_start[id + 1];
+        const int e0 = L.seg_lo[id], e1 = L.seg_hi[id];
         float acc = 0.f;
         for (int e = e0; e < e1; e++) acc = __fadd_rn(acc, L.bary[L.vals[e]]);
         val[id] = acc;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void crf_splat4_kernel(const CrfLattice L, con
         const f32x4* Q4 = reinterpret_cast<const f32x4*>(Q + im.qoff);
         f32x4* V4 = reinterpret_cast<f32x4*>(val + im.voff[L.which]);
         for (int idl = slot * 32 + pl; idl < hi - lo; idl += bpx * 32) {
-            const int e0 = L.seg_start[lo + idl], e1 = L.seg_start[lo + idl + 1];
+            const int e0 = L.seg_lo[lo + idl], e1 = L.seg_hi[lo + idl];
             for (int c = c0; c < K4; c += 8) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 for (int e = e0; e < e1; e += 4) {
@@ -470,6 +470,41 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
     }
 }
 
+// ---- spatial renumbering.  The key sort numbers lattice points in (colour-major) key order; the
+// iteration kernels are gather-bound, so the points of each image are renumbered by the pixel index of
+// their FIRST contributor (row-major image order): contributors, simplex vertices of neighbouring
+// pixels and blur neighbours then sit in nearby value rows and the gathers hit L2.  Lattice ids are
+// internal: results do not depend on them.
+__global__ void first_contrib_kernel(const uint32_t* __restrict__ vals, const int* __restrict__ seg_start, int M,
+                                     uint32_t* __restrict__ fkey, uint32_t* __restrict__ fid) {
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < M; id += gridDim.x * blockDim.x) {
+        fkey[id] = vals[seg_start[id]];
+        fid[id] = (uint32_t)id;
+    }
+}
+__global__ void rank_kernel(const uint32_t* __restrict__ sorted_id, int M, int* __restrict__ rank) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) rank[sorted_id[i]] = i;
+}
+__global__ void renumber_points_kernel(const int* __restrict__ rank, const int* __restrict__ seg_start,
+                                       const int* __restrict__ n1k, const int* __restrict__ n2k, size_t cap, int M, int D1,
+                                       int* __restrict__ seg_lo, int* __restrict__ seg_hi, int* __restrict__ n1,
+                                       int* __restrict__ n2) {
+    for (int id = blockIdx.x * blockDim.x + threadIdx.x; id < M; id += gridDim.x * blockDim.x) {
+        const int nid = rank[id];
+        seg_lo[nid] = seg_start[id];
+        seg_hi[nid] = seg_start[id + 1];
+        for (int j = 0; j < D1; j++) {
+            const int a = n1k[(size_t)j * cap + id], b = n2k[(size_t)j * cap + id];
+            n1[(size_t)j * cap + nid] = a >= 0 ? rank[a] : -1;
+            n2[(size_t)j * cap + nid] = b >= 0 ? rank[b] : -1;
+        }
+    }
+}
+__global__ void renumber_entries_kernel(const int* __restrict__ rank, size_t n, int* __restrict__ offset) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        offset[i] = rank[offset[i]];
+}
+
 // ------------------------------------------------------------------------------------------ host
 static inline int ok() { return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP; }
 
@@ -486,8 +521,8 @@ size_t crf_sort_temp_bytes(size_t max_entries, int max_images) {
 // Scratch arrays (keys/vals double buffers, head, incl, temp) are caller-provided.
 int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
                       int B, size_t ent_total, int max_pixels, const int* d_seg_begin, const int* d_seg_end,
-                      uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, void* temp,
-                      size_t temp_bytes, int* d_range_err, hipStream_t s) {
+                      uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
+                      void* temp, size_t temp_bytes, int* d_range_err, hipStream_t s) {
     const int nb = (max_pixels + 255) / 256 < 512 ? (max_pixels + 255) / 256 : 512;
     if (D == 2)
         hipLaunchKernelGGL((lattice_embed_kernel<2>), dim3(nb, B), dim3(256), 0, s, d_imgs, d_rgb, sxy, srgb, L.bary, keys_a, vals_a, d_range_err);
@@ -512,9 +547,28 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     hipLaunchKernelGGL(scatter_ids_kernel, dim3(nbe, B), dim3(256), 0, s, keys_b, L.vals, head, incl, d_imgs, D + 1, B,
                        ent_total, L.offset, L.seg_start, L.ukeys, L.idbase);
     if (D == 2)
-        hipLaunchKernelGGL((neighbors_kernel<2>), dim3(nbe, B), dim3(256), 0, s, L.ukeys, L.idbase, L.cap, L.n1, L.n2);
+        hipLaunchKernelGGL((neighbors_kernel<2>), dim3(nbe, B), dim3(256), 0, s, L.ukeys, L.idbase, L.cap, n1k, n2k);
     else
-        hipLaunchKernelGGL((neighbors_kernel<5>), dim3(nbe, B), dim3(256), 0, s, L.ukeys, L.idbase, L.cap, L.n1, L.n2);
+        hipLaunchKernelGGL((neighbors_kernel<5>), dim3(nbe, B), dim3(256), 0, s, L.ukeys, L.idbase, L.cap, n1k, n2k);
+    // spatial renumbering (needs the lattice size on the host: one small read-back per build)
+    int M = 0;
+    if (hipMemcpyAsync(&M, L.idbase + B, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return PNP_ERR_HIP;
+    if (hipStreamSynchronize(s) != hipSuccess) return PNP_ERR_HIP;
+    if (M <= 0 || (size_t)M > ent_total) return PNP_ERR_STATE;
+    uint32_t* fkey = reinterpret_cast<uint32_t*>(keys_a);
+    uint32_t* fid = fkey + ent_total;
+    uint32_t* skey = reinterpret_cast<uint32_t*>(keys_b);
+    uint32_t* sid = skey + ent_total;
+    int* rank = head;
+    hipLaunchKernelGGL(first_contrib_kernel, dim3(1024), dim3(256), 0, s, L.vals, L.seg_start, M, fkey, fid);
+    int pv_bits = 1;
+    while (((size_t)1 << pv_bits) < ent_total) pv_bits++;
+    tb = temp_bytes;
+    if (hipcub::DeviceRadixSort::SortPairs(temp, tb, fkey, skey, fid, sid, M, 0, pv_bits, s) != hipSuccess) return PNP_ERR_HIP;
+    hipLaunchKernelGGL(rank_kernel, dim3(1024), dim3(256), 0, s, sid, M, rank);
+    hipLaunchKernelGGL(renumber_points_kernel, dim3(1024), dim3(256), 0, s, rank, L.seg_start, n1k, n2k, L.cap, M, D + 1,
+                       L.seg_lo, L.seg_hi, L.n1, L.n2);
+    hipLaunchKernelGGL(renumber_entries_kernel, dim3(2048), dim3(256), 0, s, rank, ent_total, L.offset);
     return ok();
 }
 

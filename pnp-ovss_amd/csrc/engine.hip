@@ -116,6 +116,7 @@ struct pnp_engine {
         CrfLattice lat[2]{};
         uint64_t *keys_a = nullptr, *keys_b = nullptr;
         uint32_t* vals_a = nullptr;
+        int *n1k = nullptr, *n2k = nullptr;
         int *head = nullptr, *incl = nullptr, *seg_begin[2] = {nullptr, nullptr}, *seg_end[2] = {nullptr, nullptr}, *range_err = nullptr;
         void* sort_tmp = nullptr;
         size_t sort_tmp_bytes = 0;
@@ -877,6 +878,8 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
         KCHK(e, dalloc(e, &L.vals, cap));
         KCHK(e, dalloc(e, &L.offset, cap));
         KCHK(e, dalloc(e, &L.seg_start, cap + 1));
+        KCHK(e, dalloc(e, &L.seg_lo, cap));
+        KCHK(e, dalloc(e, &L.seg_hi, cap));
         KCHK(e, dalloc(e, &L.ukeys, cap));
         KCHK(e, dalloc(e, &L.idbase, B + 1));
         KCHK(e, dalloc(e, &L.n1, cap * D1));
@@ -890,6 +893,8 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     KCHK(e, dalloc(e, &p.vals_a, cap6));
     KCHK(e, dalloc(e, &p.head, cap6));
     KCHK(e, dalloc(e, &p.incl, cap6));
+    KCHK(e, dalloc(e, &p.n1k, cap6 * 6));
+    KCHK(e, dalloc(e, &p.n2k, cap6 * 6));
     KCHK(e, dalloc(e, &p.range_err, 1, true));
     p.sort_tmp_bytes = crf_sort_temp_bytes(cap6, max_batch);
     char* st = nullptr;
@@ -1013,7 +1018,7 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
             HIPCHK(e, hipStreamSynchronize(s));
             KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
                                       p.maxHW, p.seg_begin[t], p.seg_end[t], p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
-                                      p.sort_tmp, p.sort_tmp_bytes, p.range_err, s));
+                                      p.n1k, p.n2k, p.sort_tmp, p.sort_tmp_bytes, p.range_err, s));
             KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.maxHW, p.va, p.vb, p.norm[t], s));
         }
         int err = 0;

@@ -28,7 +28,9 @@ struct CrfLattice {
     float* bary;       // [entries] barycentric weight per (pixel, vertex)
     uint32_t* vals;    // [entries] sorted (pixel, vertex) indices = contributor lists
     int* offset;       // [entries] lattice id per (pixel, vertex)
-    int* seg_start;    // [M+1] first sorted entry of each lattice point
+    int* seg_start;    // [M+1] first sorted entry of each lattice point, key order (build scratch)
+    int* seg_lo;       // [M] contributor range of each lattice point (final, spatial numbering)
+    int* seg_hi;
     uint64_t* ukeys;   // [M] sorted unique packed keys
     int* idbase;       // [B+1] first lattice id of each image
     int* n1;           // [(d+1) * cap]
@@ -83,8 +85,8 @@ int confusion_hist(const uint8_t* labels, const float* gt, const PostDesc* desc,
 size_t crf_sort_temp_bytes(size_t max_entries, int max_images);
 int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
                       int B, size_t ent_total, int max_pixels, const int* d_seg_begin, const int* d_seg_end,
-                      uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, void* temp,
-                      size_t temp_bytes, int* d_range_err, hipStream_t s);
+                      uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
+                      void* temp, size_t temp_bytes, int* d_range_err, hipStream_t s);
 int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, float* va, float* vb,
                      float* norm_out, hipStream_t s);
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
