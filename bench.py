@@ -158,6 +158,14 @@ def main():
         dist.gather(state["ln"], gathered, dst=0)                # mask-gather of uint8 label maps to rank 0
 
     if rank == 0:
+        # HBM-side bytes per launch of the same kernels from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE / WRITE_SIZE cannot be read live; see profiles/r01_gemm_traffic.json)
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if a.dtype == "bf16" and os.path.exists(tf):
+            ks = json.load(open(tf))["kernels"].values()
+            n = sum(k["launches_profiled"] for k in ks)
+            traffic = sum(k["traffic_bytes_per_launch"] * k["launches_profiled"] for k in ks) / max(n, 1)
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = MFMA_PEAK_TFLOPS[a.dtype]
         out = {
@@ -172,8 +180,9 @@ def main():
                                    "BLIP-ITM-large random weights, layer 8 head 9, drop_iter 4, threshold 0.15, "
                                    + ("N-drop" if a.skip_1drop else "1-drop + N-drop") + " blur+CRF",
                        "images_per_step_per_gpu": B, "sharding": "images across ranks, no per-step collective"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_big_kernel<{a.dtype},128,128,64,64,2> (LDS-DMA ring GEMM)", "achieved": achieved,
-                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_big_kernel<{a.dtype}> (LDS-DMA ring GEMM; 128x128 tiles for K=1024, 256x256 for K=4096)", "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, offline pass)",
                          "launches": launches, "avg_launch_ms": ms / max(launches, 1),
                          "algorithmic_flop_per_launch": flops / max(launches, 1)},
         }
