@@ -13,14 +13,14 @@ maps = (rng.random((B, 24, 21, 21), dtype=np.float32) ** 4)
 d_maps = torch.from_numpy(maps).cuda()
 plans = [[([i], 1) for i in range(20)]] * B
 luts = [list(range(21))] * B
-for noise in (12, 4, 0):
+for noise in (4,):
     g = np.random.default_rng([1234, 7])
     nb = IMG // 8
     coarse = g.integers(0, 256, size=(B, nb, nb, 3))
     fine = g.integers(-noise, noise + 1, size=(B, IMG, IMG, 3))
     rgb = np.clip(np.repeat(np.repeat(coarse, 8, 1), 8, 2) + fine, 0, 255).astype(np.uint8)
     d_rgb = torch.from_numpy(rgb.reshape(-1)).cuda()
-    for chunk in (35, 8, 4, 2, 1):
+    for chunk in (35, 24, 18, 16, 12, 8):
         e = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, bf16=True)
         e.post_reserve(B, B * IMG * IMG, IMG * IMG, K, chunk)
         e.post_prepare([(IMG, IMG)] * B, plans, luts, [True] * B, rgb=d_rgb, gt=None, want_crf=True)
