@@ -156,6 +156,16 @@ int pnp_op_gemm_ex(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, 
                    int32_t ldo_t, int32_t mode, void* stream);
 int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                      float* d_y, void* stream);
+/* Cross-attention over the image tokens as one operator (B/med.py:229-283 forward, its autograd backward):
+ *   mode 0: probs = softmax(x . K^T / 8) -> d_probs ; out = probs . V          (d_nat = K rows, d_tr = V^T)
+ *   mode 1: dP = dctx . V^T ; dS = probs (dP - rowsum(dP probs)) ; out = dS . K / 8   (d_nat = V rows, d_tr = K^T,
+ *           d_probs read)
+ *   mode 2: d_probs = dctx . V^T                                               (d_nat = V rows)
+ * d_nat [B*N, ld_nat] token-major; d_tr [heads*64, ld_tr] with element (h*64+d, b*n_pad + n); x / out [B*L, ld]
+ * in the compute type (bf16 or f32); d_probs fp32 [B, heads, L, n_stride]. head_dim is 64. */
+int pnp_op_xattn(int32_t bf16, int32_t mode, const void* d_nat, int32_t ld_nat, const void* d_tr, int32_t ld_tr,
+                 int32_t n_pad, const void* d_x, int32_t ldx, void* d_out, int32_t ldo, float* d_probs, int32_t n_stride,
+                 int32_t B, int32_t L, int32_t N, int32_t heads, void* stream);
 int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -1135,6 +1135,11 @@ extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, siz
     if (n == "dP") return set(e->dPc, B * e->nh * L * (size_t)e->Nst * 4);
     if (n == "h_last") return set(e->ta[e->TL - 1].h_out, B * L * (size_t)e->H * 4);
     if (n == "dropped") return set(e->dropped, B * (size_t)e->PP);
+    if (n == "P_last" && e->ta[e->TL - 1].Pc) return set(e->ta[e->TL - 1].Pc, B * e->nh * L * (size_t)e->Nst * 4);
+    if (n == "Kt" && e->Kt) return set(e->Kt, (size_t)(e->TL - e->SL - 1) * e->H * B * e->Npad * e->esz);
+    if (n == "Vt") return set(e->Vt, (size_t)e->TL * e->H * B * e->Npad * e->esz);
+    if (n == "dq_xattn") return set(e->dqc, B * L * (size_t)e->H * e->esz);
+    if (n == "dctx_xattn") return set(e->dctxc, B * L * (size_t)e->H * e->esz);
     if (p.reserved) {
         const size_t mk = (size_t)p.max_total_pix * p.maxK * 4;
         const size_t mq = (size_t)p.max_total_pix * p.maxKp * 4;
@@ -1198,6 +1203,15 @@ extern "C" int pnp_op_gemm_ex(int32_t bf, const void* d_A, int32_t lda, const vo
 extern "C" int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                                 float* d_y, void* stream) {
     return layernorm(0, d_x, d_w, d_b, eps, rows, D, d_y, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pnp_op_xattn(int32_t bf16, int32_t mode, const void* d_nat, int32_t ld_nat, const void* d_tr, int32_t ld_tr,
+                            int32_t n_pad, const void* d_x, int32_t ldx, void* d_out, int32_t ldo, float* d_probs,
+                            int32_t n_stride, int32_t B, int32_t L, int32_t N, int32_t heads, void* stream) {
+    if (!d_nat || !d_x || !d_probs || mode < 0 || mode > 2 || (mode != 2 && (!d_tr || !d_out))) return PNP_ERR_ARG;
+    if (B <= 0 || L <= 0 || N <= 0 || heads <= 0) return PNP_ERR_ARG;
+    return xattn(bf16, mode, d_nat, ld_nat, d_tr, ld_tr, n_pad, d_x, ldx, d_out, ldo, d_probs, n_stride, B, L, N, heads,
+                 (hipStream_t)stream);
 }
 
 extern "C" int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream) {

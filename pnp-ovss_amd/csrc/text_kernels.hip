@@ -190,24 +190,24 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
 // a2t: transposed operand [64 rows per head..., ld2], element (h*64+d, b*Npad + n)
 // x  : per-token operand  [B*L, ldx] (q or dctx), T
 // out: [B*L, ldo] T (ctx or dq)
-template <typename T, int MODE, int NW, int TPW>
+template <typename T, int MODE, int NW, int TPW, int QT>
 __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1, int ld1, const T* __restrict__ a2t,
                                                         int ld2, int Npad, const T* __restrict__ x, int ldx,
                                                         T* __restrict__ out, int ldo, float* __restrict__ pbuf,
                                                         int Nst, int L, int N, int nheads) {
-    __shared__ float red[NW][32];
-    __shared__ float red2[NW][32];
-    __shared__ __attribute__((aligned(16))) float obuf[64][33];
-    const int h = blockIdx.x, b = blockIdx.y, l0 = blockIdx.z * 32;
+    __shared__ float red[NW][QT * 16];
+    __shared__ float red2[NW][QT * 16];
+    __shared__ __attribute__((aligned(16))) float obuf[64][QT * 16 + 1];
+    const int h = blockIdx.x, b = blockIdx.y, l0 = blockIdx.z * (QT * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, q = lane >> 4;
     const int nkt = (N + 15) / 16;
 
     // per-token operand fragments for the two 16-query tiles of this block
-    Frag<T> fx[2][2];
-    int lrow[2];
+    Frag<T> fx[QT][2];
+    int lrow[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         int l = l0 + qt * 16 + r;
         lrow[qt] = l;
         l = l < L ? l : L - 1;
@@ -216,12 +216,12 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
         glb_frag(fx[qt][1], xp, 1, q);
     }
     // first product: rows = image tokens of this wave's tiles, cols = queries
-    f32x4 s[TPW][2];
+    f32x4 s[TPW][QT];
 #pragma unroll
     for (int i = 0; i < TPW; i++) {
         const int kt = wave * TPW + i;
-        s[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) s[i][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (kt < nkt) {
             int n = kt * 16 + r;
             n = n < N ? n : N - 1;
@@ -230,14 +230,14 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
             for (int ks = 0; ks < 2; ks++) {
                 Frag<T> fa;
                 glb_frag(fa, ap, ks, q);
-                mma16(s[i][0], fa, fx[0][ks]);
-                mma16(s[i][1], fa, fx[1][ks]);
+#pragma unroll
+                for (int qt = 0; qt < QT; qt++) mma16(s[i][qt], fa, fx[qt][ks]);
             }
         }
     }
-    float* prow[2];
+    float* prow[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         const int l = lrow[qt] < L ? lrow[qt] : L - 1;
         prow[qt] = pbuf ? pbuf + (((size_t)b * nheads + h) * L + l) * Nst : nullptr;
     }
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
             const int kt = wave * TPW + i;
             if (kt >= nkt) continue;
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++)
+            for (int qt = 0; qt < QT; qt++)
                 if (lrow[qt] < L) *reinterpret_cast<f32x4*>(prow[qt] + kt * 16 + q * 4) = s[i][qt];
         }
         return;
@@ -256,12 +256,14 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
 
     if (MODE == 0) {
         // softmax over all N keys of each query column
-        float mx[2] = {-INFINITY, -INFINITY};
+        float mx[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) mx[qt] = -INFINITY;
 #pragma unroll
         for (int i = 0; i < TPW; i++) {
             const int kt = wave * TPW + i;
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++)
+            for (int qt = 0; qt < QT; qt++)
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int n = kt * 16 + q * 4 + e;
@@ -271,16 +273,17 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
                 }
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 16, 64));
             mx[qt] = fmaxf(mx[qt], __shfl_xor(mx[qt], 32, 64));
             if (q == 0) red[wave][qt * 16 + r] = mx[qt];
         }
         __syncthreads();
-        float sum[2] = {0.f, 0.f};
+        float sum[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             float m = -INFINITY;
+            sum[qt] = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; w++) m = fmaxf(m, red[w][qt * 16 + r]);
 #pragma unroll
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
         }
         __syncthreads();
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; w++) tot += red2[w][qt * 16 + r];
@@ -312,13 +315,15 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
         }
     } else {
         // MODE 1: dS = P * (dP - rowsum(dP * P))
-        float dot[2] = {0.f, 0.f};
-        f32x4 pv[TPW][2];
+        float dot[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) dot[qt] = 0.f;
+        f32x4 pv[TPW][QT];
 #pragma unroll
         for (int i = 0; i < TPW; i++) {
             const int kt = wave * TPW + i;
 #pragma unroll
-            for (int qt = 0; qt < 2; qt++) {
+            for (int qt = 0; qt < QT; qt++) {
                 pv[i][qt] = (kt < nkt) ? *reinterpret_cast<const f32x4*>(prow[qt] + kt * 16 + q * 4)
                                        : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -330,14 +335,14 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
             }
         }
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             dot[qt] += __shfl_xor(dot[qt], 16, 64);
             dot[qt] += __shfl_xor(dot[qt], 32, 64);
             if (q == 0) red[wave][qt * 16 + r] = dot[qt];
         }
         __syncthreads();
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             float tot = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; w++) tot += red[w][qt * 16 + r];
@@ -349,20 +354,20 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
     }
 
     // second product: out^T[d][l] = sum_n a2t[d][n] * s^T[n][l], k-steps pair this wave's tiles
-    f32x4 o[4][2];
+    f32x4 o[4][QT];
 #pragma unroll
     for (int dt = 0; dt < 4; dt++) {
-        o[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        o[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qt = 0; qt < QT; qt++) o[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < TPW; i += 2) {
         const int ktA = wave * TPW + i, ktB = ktA + 1;
         if (ktA >= nkt) continue;
         const bool hasB = (i + 1 < TPW) && (ktB < nkt);
-        Frag<T> fp[2];
+        Frag<T> fp[QT];
 #pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             if (i + 1 < TPW) pack_p(fp[qt], s[i][qt], hasB ? s[i + 1][qt] : f32x4{0.f, 0.f, 0.f, 0.f});
             else pack_p(fp[qt], s[i][qt], f32x4{0.f, 0.f, 0.f, 0.f});
         }
@@ -371,8 +376,8 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
             const T* vp = a2t + (size_t)(h * 64 + dt * 16 + r) * ld2 + (size_t)b * Npad;
             Frag<T> fv;
             glb_frag_pair(fv, vp + ktA * 16 + q * 4, vp + (hasB ? ktB : ktA) * 16 + q * 4);
-            mma16(o[dt][0], fv, fp[0]);
-            mma16(o[dt][1], fv, fp[1]);
+#pragma unroll
+            for (int qt = 0; qt < QT; qt++) mma16(o[dt][qt], fv, fp[qt]);
         }
     }
     // deterministic cross-wave reduction through LDS
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
 #pragma unroll
             for (int dt = 0; dt < 4; dt++)
 #pragma unroll
-                for (int qt = 0; qt < 2; qt++)
+                for (int qt = 0; qt < QT; qt++)
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         float* p = &obuf[dt * 16 + q * 4 + e][qt * 16 + r];
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(NW * 64) void xattn_kernel(const T* __restrict__ a1
         }
         __syncthreads();
     }
-    for (int i = tid; i < 32 * 64; i += NW * 64) {
+    for (int i = tid; i < QT * 16 * 64; i += NW * 64) {
         const int l = i >> 6, d = i & 63;
         if (l0 + l < L) out[((size_t)b * L + l0 + l) * ldo + h * 64 + d] = from_f32<T>(obuf[d][l]);
     }
@@ -522,12 +527,13 @@ template <typename T, int MODE>
 static int xattn_launch(const void* a1, int ld1, const void* a2t, int ld2, int Npad, const void* x, int ldx, void* out,
                         int ldo, float* pbuf, int Nst, int B, int L, int N, int nheads, hipStream_t s) {
     const int nkt = (N + 15) / 16;
-    dim3 grid(nheads, B, (L + 31) / 32);
     if (nkt <= 4 * 8) {
-        hipLaunchKernelGGL((xattn_kernel<T, MODE, 4, 8>), grid, dim3(256), 0, s, (const T*)a1, ld1, (const T*)a2t, ld2,
+        dim3 grid(nheads, B, (L + 31) / 32);
+        hipLaunchKernelGGL((xattn_kernel<T, MODE, 4, 8, 2>), grid, dim3(256), 0, s, (const T*)a1, ld1, (const T*)a2t, ld2,
                            Npad, (const T*)x, ldx, (T*)out, ldo, pbuf, Nst, L, N, nheads);
     } else if (nkt <= 16 * 10) {
-        hipLaunchKernelGGL((xattn_kernel<T, MODE, 16, 10>), grid, dim3(1024), 0, s, (const T*)a1, ld1, (const T*)a2t,
+        dim3 grid(nheads, B, (L + 15) / 16);
+        hipLaunchKernelGGL((xattn_kernel<T, MODE, 16, 10, 1>), grid, dim3(1024), 0, s, (const T*)a1, ld1, (const T*)a2t,
                            ld2, Npad, (const T*)x, ldx, (T*)out, ldo, pbuf, Nst, L, N, nheads);
     } else {
         return PNP_ERR_ARG;

@@ -106,6 +106,60 @@ def test_layernorm():
 # ------------------------------------------------------------------------------------------ model
 
 @pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("N,L", [(26, 7), (197, 11), (577, 11), (577, 40), (2304, 11), (2305, 20), (2560, 5)])
+def test_cross_attention_operator(bf16, N, L):
+    """pnp_op_xattn, all three modes, against an fp64 restatement of B/med.py:229-283 and its
+    autograd backward.  Covers both launch shapes (<=512 and <=2560 image tokens), ragged last key
+    tiles, idle waves, and rows whose upstream gradient is exactly zero.  f32: 2e-5 abs on unit-scale
+    data; bf16 operands: 3e-2."""
+    from pnp_ovss.hip import load_library
+    lib = load_library()
+    heads, B = 12, 2
+    H = heads * 64
+    Npad = (N + 63) // 64 * 64
+    g = torch.Generator().manual_seed(N * 100 + L)
+    K = torch.randn(B, N, H, generator=g) * 0.5
+    V = torch.randn(B, N, H, generator=g) * 0.5
+    q = torch.randn(B, L, H, generator=g)
+    dctx = torch.randn(B, L, H, generator=g)
+    dctx[:, 1:3] = 0
+    tdt = torch.bfloat16 if bf16 else torch.float32
+    rnd = (lambda a: a.to(tdt).float()) if bf16 else (lambda a: a)
+    K, V, q, dctx = rnd(K), rnd(V), rnd(q), rnd(dctx)
+
+    def tr(a):
+        t = torch.zeros(H, B, Npad)
+        t[:, :, :N] = a.permute(2, 0, 1)
+        return t.reshape(H, B * Npad).to(tdt).contiguous().cuda()
+    d = lambda a: a.to(tdt).contiguous().cuda()
+    Kn, Vn, Kt, Vt = d(K.reshape(B * N, H)), d(V.reshape(B * N, H)), tr(K), tr(V)
+    qd, dcd = d(q.reshape(B * L, H)), d(dctx.reshape(B * L, H))
+    P = torch.zeros(B, heads, L, Npad, device="cuda")
+    dP = torch.zeros(B, heads, L, Npad, device="cuda")
+    ctx = torch.zeros(B * L, H, device="cuda", dtype=tdt)
+    dq = torch.zeros(B * L, H, device="cuda", dtype=tdt)
+    p = lambda t: t.data_ptr()
+    bf = 1 if bf16 else 0
+    assert lib.pnp_op_xattn(bf, 0, p(Kn), H, p(Vt), B * Npad, Npad, p(qd), H, p(ctx), H, p(P), Npad, B, L, N, heads, None) == 0
+    assert lib.pnp_op_xattn(bf, 2, p(Vn), H, None, 0, Npad, p(dcd), H, None, 0, p(dP), Npad, B, L, N, heads, None) == 0
+    assert lib.pnp_op_xattn(bf, 1, p(Vn), H, p(Kt), B * Npad, Npad, p(dcd), H, p(dq), H, p(P), Npad, B, L, N, heads, None) == 0
+    torch.cuda.synchronize()
+    f = lambda a: a.double().view(B, -1, heads, 64).permute(0, 2, 1, 3)
+    Kh, Vh, qh, dch = f(K), f(V), f(q), f(dctx)
+    Pr = (qh @ Kh.transpose(-1, -2) / 8).softmax(-1)
+    ctxr = (Pr @ Vh).permute(0, 2, 1, 3).reshape(B * L, H)
+    dPr = dch @ Vh.transpose(-1, -2)
+    dS = Pr * (dPr - (dPr * Pr).sum(-1, keepdim=True))
+    dqr = (dS @ Kh / 8).permute(0, 2, 1, 3).reshape(B * L, H)
+    tol = 3e-2 if bf16 else 2e-5
+    for name, got, ref in (("probs", P[..., :N], Pr), ("ctx", ctx, ctxr), ("dP", dP[..., :N], dPr), ("dq", dq, dqr)):
+        err = float((got.cpu().double() - ref).abs().max())
+        assert np.isfinite(err) and err <= tol * max(1.0, float(ref.abs().max())), (name, err)
+    assert float(P[..., N:].abs().max()) == 0.0 if Npad > N else True
+    assert float(dq.float().view(B, L, H)[:, 1:3].abs().max()) == 0.0      # zero upstream rows stay exactly zero
+
+
+@pytest.mark.parametrize("bf16", [False, True])
 def test_vit_forward_small(bf16):
     cfg = C.blip_itm_small(64)
     W = synth.synth_state_dict(cfg, 3)
@@ -436,3 +490,33 @@ def test_end_to_end_f32_labels_vs_reference_run(fname):
     torch.cuda.synchronize()
     bad = sum(int((got[i].cpu().numpy().astype(np.float32) != ln[i]).sum()) for i in range(B))
     assert bad <= 0.003 * total, bad
+
+
+def test_gradcam_768_geometry_vs_oracle():
+    """BASELINE config 5 geometry (img_size 768 -> 48x48 patches, 2305 image tokens): exercises the
+    many-key cross-attention variant and multi-tile ViT attention; fp32 mode vs the oracle."""
+    cfg = C.blip_itm_small(768)
+    W = synth.synth_state_dict(cfg, 2)
+    _, imgs = synth.synth_images(1, 768, seed=9)
+    ids, mask = synth.synth_tokens(cfg, [6], seed=3)
+    L = int(mask.sum(1).max())
+    e = _engine(cfg, 2, False, max_batch=1, max_text_len=16)
+    out, logits = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 9)
+    torch.cuda.synchronize()
+    maps, ref_logits, _ = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7])
+    ref = maps[7][:, 9]
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+    assert np.abs(_norm01(out.cpu().numpy()[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < 5e-3
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, atol=2e-2)
+    # 768-sized post-process (blur radius 154) vs the oracle, bit-exact
+    e.post_reserve(1, 768 * 768, 768 * 768, 8, 0)
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, size=(768, 768, 3), dtype=np.uint8)
+    plans, luts = [[([i], 1) for i in range(6)]], [list(range(7))]
+    e.post_prepare([(768, 768)], plans, luts, [True], rgb=_dev(rgb.reshape(-1)), gt=None, want_crf=False)
+    labels = e.split_labels(e.postprocess(out, 0.15, False, "blur"))
+    torch.cuda.synchronize()
+    merged = OP.merge_tokens(out.cpu().numpy()[0], [f"t{i}" for i in range(6)], 6)
+    pre = OP.threshold_upsample(merged, 768, 768, 0.15, False, True)
+    lab = OP.postprocess("blur", pre, None, (768, 768))
+    np.testing.assert_array_equal(labels[0].cpu().numpy().astype(np.float32), lab)
