@@ -166,6 +166,10 @@ int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float
 int pnp_op_xattn(int32_t bf16, int32_t mode, const void* d_nat, int32_t ld_nat, const void* d_tr, int32_t ld_tr,
                  int32_t n_pad, const void* d_x, int32_t ldx, void* d_out, int32_t ldo, float* d_probs, int32_t n_stride,
                  int32_t B, int32_t L, int32_t N, int32_t heads, void* stream);
+/* Diagnostics: with PNP_GEMM_STAMPS=1 in the environment the wide-tile GEMM records, per workgroup, the
+ * shader clock (slots 0-3) and the 100 MHz wall clock (slots 4-7) at kernel start, after the first slab
+ * landed, after the main loop and after the epilogue; this copies the last launch's stamps to the host. */
+int pnp_dbg_gemm_stamps(uint64_t* host_out, int32_t max_blocks);
 int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -1214,6 +1214,10 @@ extern "C" int pnp_op_xattn(int32_t bf16, int32_t mode, const void* d_nat, int32
                  (hipStream_t)stream);
 }
 
+extern "C" int pnp_dbg_gemm_stamps(uint64_t* host_out, int32_t max_blocks) {
+    return gemm_read_stamps((unsigned long long*)host_out, max_blocks);
+}
+
 extern "C" int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream) {
     return cast_f32(to_bf16, d_in, d_out, (size_t)n, (hipStream_t)stream);
 }

@@ -24,6 +24,7 @@ struct GemmArgs {
     int ld_aux = 0;
     int row_div = 0;               // >0: patch rows -> token rows b*(row_div+1)+1+p, resid = pos_embed
     int col_div = 0, col_pad = 0;  // >0: output column n -> (n / col_div) * col_pad + n % col_div
+    unsigned long long* stamps = nullptr;   // diagnostics (PNP_GEMM_STAMPS): per-workgroup clock stamps, 8 per block
     int ablate = 0;                // timing experiments only (PNP_GEMM_ABLATE): 1 = no steady-state DMA, 2 = no MFMA
 };
 
@@ -39,5 +40,6 @@ struct GemmProfile {
     double flops = 0;
 };
 GemmProfile& gemm_profile();
+int gemm_read_stamps(unsigned long long* host_out, int max_blocks);
 
 }  // namespace pnp

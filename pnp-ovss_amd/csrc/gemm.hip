@@ -210,6 +210,13 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
         }
     }
 
+    auto stamp = [&](int slot) {
+        if (g.stamps && tid == 0) {
+            g.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+            g.stamps[(size_t)blockIdx.x * 8 + 4 + slot] = wall_clock64();
+        }
+    };
+    stamp(0);
     const int nk = g.K / BK;
     constexpr int KSTEPS = BK / 32;
     auto read_frags = [&](Frag<T>* fa, Frag<T>* fb, int kt, int ks) {
@@ -263,6 +270,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
         else if (NS > 2 && nk == NS - 1) PNP_WAIT_VM((NS > 2 ? NS - 2 : 0) * NDMA);
         else PNP_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
+        stamp(1);
         Frag<T> fa[TM], fb0[TN], fb1[TN];
         read_frags(fa, fb0, 0, 0);
         for (int kt = 0; kt < nk; kt++) {
@@ -305,6 +313,7 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
             }
         }
     }
+    stamp(2);
 #pragma unroll
     for (int j = 0; j < TM; j++) {
         const int m = m0 + wm * WTM + j * 16 + r;
@@ -316,6 +325,10 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
             if (n >= g.Nvalid) continue;
             store_frag<T>(g, rc, acc[i][j], m, n, n + 3 < g.Nvalid);
         }
+    }
+    if (g.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);
     }
 }
 
@@ -331,6 +344,265 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>), dim3(nbm * nbn), dim3((BM / WTM) * (BN / WTN) * 64), smem, s, g);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------
+// Wide-tile bf16 kernel: 256 x 256 block tile, 8 waves (2 x 4) of 128 x 64, v_mfma_f32_32x32x16_bf16.
+//
+// Why this shape: one CU takes in at most 64 B/clk of global data (TA / vector L1 path) and every
+// LDS-DMA piece stalls its issuing wave for 60+ cycles, so a 128 x 128 tile (32 KB per 512 MFMA
+// cycles) is ingest-bound.  At 256 x 256 the same 64 KB slab feeds 2048 MFMA cycles, the 32x32x16
+// form halves the LDS fragment bytes per FLOP and leaves 24 free issue cycles per MFMA, and two
+// waves per SIMD (256 registers each: 128 accumulators + two fragment sets) cover each other's
+// DMA-issue stalls.
+//
+// Schedule per 64-deep slab (4 k16 sub-steps, fragments double-buffered in registers):
+//   MFMA(s0) || read(s1);  MFMA(s1) || read(s2);  MFMA(s2) || read(s3);
+//   wait own reads + own DMA of slab t+1; s_barrier      <- the only barrier per slab
+//   issue DMA of slab t+2 into the slot just vacated || read(s0 of slab t+1) || MFMA(s3)
+// so the MFMAs of s3 (operands already in registers) cover the barrier hand-over, the DMA issue and
+// the first fragment reads of the next slab, and every DMA has a whole slab time to land.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// EPI selects the (compile-time) epilogue: 0 = +bias -> bf16, 1 = +bias, GELU -> bf16, 2 = +bias +residual -> fp32.
+enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2 };
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, ROWB = 128, BK = 64, STAGE = (BM + BN) * ROWB;
+    constexpr int TM = 4, TN = 2;                   // 32 x 32 tiles per wave: 128 (m) x 64 (n)
+    constexpr int A_DMA = 4, B_DMA = 4, NDMA = 8;   // 8-row pieces per wave per slab
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
+    int bm, bn;
+    tile_coords<4>(blockIdx.x, nbm, nbn, bm, bn);
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const char* Ab = reinterpret_cast<const char*>(g.A);
+    const char* Bb = reinterpret_cast<const char*>(g.B);
+    uint32_t soff[NDMA];
+    {
+        const uint32_t lda_b = (uint32_t)g.lda * 2, ldb_b = (uint32_t)g.ldb * 2;
+        const int pc = lane & 7;
+#pragma unroll
+        for (int i = 0; i < A_DMA; i++) {
+            const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
+            int gr = m0 + row;
+            gr = gr < g.M ? gr : g.M - 1;
+            soff[i] = (uint32_t)gr * lda_b + swz_chunk<ROWB>(row, pc) * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < B_DMA; i++) {
+            const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
+            int gr = n0 + row;
+            gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
+            soff[A_DMA + i] = (uint32_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
+        }
+    }
+    auto issue_one = [&](int kt, int i) {
+        char* stage = smem + (kt & 1) * STAGE;
+        const uint32_t koff = (uint32_t)kt * ROWB;
+        const char* base = i < A_DMA ? Ab : Bb;
+        const int d = i < A_DMA ? (wave * A_DMA + i) * 8 * ROWB : BM * ROWB + (wave * B_DMA + (i - A_DMA)) * 8 * ROWB;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[i] + koff)),
+                                         (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
+    };
+
+    // lane owns row m = .. + l32 and, per 4-register group gq, columns 8 gq + 4 hi .. + 3 of each 32 x 32
+    // tile (operands are swapped at the MFMA: D = Btile * Atile^T)
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TM; j++)
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // fragment addresses: row = tile row + l32, logical chunk = 2 ks + hi; the swizzle term depends on
+    // l32 only (tile row offsets are multiples of 32), so one XOR per k16 sub-step serves all tiles
+    const int sw = (l32 >> 1) & 7;
+    const int a_row_off = (wm * 128 + l32) * ROWB, b_row_off = BM * ROWB + (wn * 64 + l32) * ROWB;
+    auto read_frags = [&](bf16x8* fa, bf16x8* fb, int kt, int ks) {
+        const char* st = smem + (kt & 1) * STAGE + (((ks * 2 + hi) ^ sw) << 4);
+#pragma unroll
+        for (int j = 0; j < TM; j++) fa[j] = *reinterpret_cast<const bf16x8*>(st + a_row_off + j * 32 * ROWB);
+#pragma unroll
+        for (int i = 0; i < TN; i++) fb[i] = *reinterpret_cast<const bf16x8*>(st + b_row_off + i * 32 * ROWB);
+    };
+    auto mma_all = [&](const bf16x8* fa, const bf16x8* fb) {
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+    };
+    // interleave hint: one LDS read behind each of the first six MFMAs of a sub-step
+    auto sched_plain = [&]() {
+#pragma unroll
+        for (int u = 0; u < TM + TN; u++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+    };
+
+    auto stamp = [&](int slot) {
+        if (g.stamps && tid == 0) {
+            g.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+            g.stamps[(size_t)blockIdx.x * 8 + 4 + slot] = wall_clock64();
+        }
+    };
+    stamp(0);
+    const int nk = g.K / BK;
+#pragma unroll
+    for (int i = 0; i < NDMA; i++) issue_one(0, i);
+    PNP_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    stamp(1);
+    if (nk > 1) {
+#pragma unroll
+        for (int i = 0; i < NDMA; i++) issue_one(1, i);
+    }
+    bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    read_frags(fa0, fb0, 0, 0);
+    // sub-steps s0..s2 of slab kt: MFMAs on one fragment set, reads of the next sub-step into the other
+    auto body012 = [&](int kt) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_frags(fa1, fb1, kt, 1);
+        mma_all(fa0, fb0);
+        sched_plain();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_frags(fa0, fb0, kt, 2);
+        mma_all(fa1, fb1);
+        sched_plain();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        read_frags(fa1, fb1, kt, 3);
+        mma_all(fa0, fb0);
+        sched_plain();
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; kt++) {                 // steady state: slab kt+2 exists
+        body012(kt);
+        PNP_WAIT_VM_LGKM(0);                    // own s3 fragments in registers, own pieces of slab kt+1 landed
+        __builtin_amdgcn_s_barrier();           // slab kt+1 complete; nobody reads slab kt's slot any more
+        read_frags(fa0, fb0, kt + 1, 0);
+#pragma unroll
+        for (int i = 0; i < NDMA; i++) issue_one(kt + 2, i);
+        mma_all(fa1, fb1);
+        // LDS-DMA writes may not be reordered against the LDS reads: reads lead, DMA pieces follow
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    }
+    if (kt + 1 < nk) {                          // second-to-last slab: nothing left to fetch
+        body012(kt);
+        PNP_WAIT_VM_LGKM(0);
+        __builtin_amdgcn_s_barrier();
+        read_frags(fa0, fb0, kt + 1, 0);
+        mma_all(fa1, fb1);
+        sched_plain();
+        kt++;
+    }
+    body012(kt);                                // last slab
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    mma_all(fa1, fb1);
+    stamp(2);
+
+    // Epilogue through LDS: the accumulator layout gives a lane 4 consecutive columns in each of 32
+    // different rows, i.e. 16-byte fragments of 32 cache lines per store instruction.  Each wave
+    // transposes its tile (two 64-row halves, fp32, rows padded by 16 B against bank conflicts)
+    // so that 16 consecutive lanes own one 64-column row segment: every global access of the
+    // epilogue is then a full 128/256-byte line.  vmcnt counts loads and stores in one in-order
+    // counter, so the residual rows of a half are all requested BEFORE its first store and no wait
+    // ever sits behind a store; the epilogue is specialised at compile time (no generic branches).
+    __syncthreads();                                    // every wave is done reading the last slab
+    constexpr int SROW = 68;                            // floats per staged row (64 + 4 pad)
+    float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SROW);
+    const int n = n0 + wn * 64 + (lane & 15) * 4;       // this lane's 4 output columns (same for every row)
+    const bool nv = n < g.Nvalid;                       // N is a multiple of 4 on this path
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int mrow0 = m0 + wm * 128 + half * 64 + (lane >> 4);
+        f32x4 rv[16];
+        if constexpr (EPI == WIDE_RESID_F32) {
+#pragma unroll
+            for (int it = 0; it < 16; it++) {
+                const int m = mrow0 + it * 4;
+                rv[it] = (m < g.M && nv) ? *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n) : bv;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const f32x16& a = acc[i][half * 2 + jj];
+                    const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
+                    *reinterpret_cast<f32x4*>(stg + (jj * 32 + l32) * SROW + i * 32 + gq * 8 + hi * 4) = v;
+                }
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 4);
+            const int m = mrow0 + it * 4;
+            v += bv;
+            if constexpr (EPI == WIDE_GELU_BF16) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
+            }
+            if constexpr (EPI == WIDE_RESID_F32) {
+                v += rv[it];
+                if (m < g.M && nv) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo + n) = v;
+            } else {
+                const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                if (m < g.M && nv) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(g.out_t) + (size_t)m * g.ldo_t + n) = pk;
+            }
+        }
+    }
+    if (g.ablate == 7) stamp(1);                        // diagnostics: stores issued, not yet acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);
+}
+
+// the wide kernel's compile-time epilogues cover the ViT block's dense layers; anything else (row / column
+// remaps, per-row bias, stashes, dual outputs) stays on the generic kernels
+static int wide_epilogue_kind(const GemmArgs& g) {
+    if (g.aux || g.row_div || g.col_div || g.bias_on_rows || (g.Nvalid & 3)) return -1;
+    if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_t && !g.out_f32) return WIDE_BF16;
+    if (g.mode == GEMM_EPI_GELU && !g.resid && g.out_t && !g.out_f32) return WIDE_GELU_BF16;
+    if (g.mode == GEMM_EPI_LINEAR && g.resid && g.out_f32 && !g.out_t) return WIDE_RESID_F32;
+    return -1;
+}
+
+template <int EPI>
+static int launch_wide(const GemmArgs& g, hipStream_t s) {
+    const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
+    const size_t smem = 8 * 64 * 68 * 4;    // 136 KB: the 2-slot ring (128 KB) or the staged epilogue
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return PNP_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_wide_kernel<EPI>, dim3(nbm * nbn), dim3(512), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
@@ -464,6 +736,18 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
+static constexpr int kStampBlocks = 8192;
+static unsigned long long*& stamp_buf() {
+    static unsigned long long* p = nullptr;
+    return p;
+}
+int gemm_read_stamps(unsigned long long* host_out, int max_blocks) {
+    if (!stamp_buf()) return PNP_ERR_STATE;
+    const int n = max_blocks < kStampBlocks ? max_blocks : kStampBlocks;
+    if (hipDeviceSynchronize() != hipSuccess) return PNP_ERR_HIP;
+    return hipMemcpy(host_out, stamp_buf(), (size_t)n * 64, hipMemcpyDeviceToHost) == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
 // Host entry.  N is rounded up to the tile internally (loads clamp, stores mask on Nvalid).
 int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return PNP_ERR_ARG;
@@ -494,20 +778,30 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     }
     const double fl = 2.0 * g.M * (double)g.N * g.K;
     g.N = (g.N + 127) / 128 * 128;
-    // The kernel is bound by what one CU can pull out of L2 / Infinity Cache (~40 GB/s measured), so
-    // the tile is chosen for arithmetic intensity against fixed per-workgroup cost:
-    //   K >= 2048 : 256 x 256 tile, 8 waves of 128 x 64, 2-slot ring (half the operand bytes per FLOP;
-    //               ~980 TFLOP/s on the fc2 shape)
-    //   otherwise : 128 x 128 tile, 4 waves of 64 x 64, 2-slot ring, software-pipelined fragments
-    //               (64 KB LDS -> two workgroups per CU, so one's prologue / epilogue hides behind the
-    //               other's main loop; best for the 16-slab K = 1024 shapes)
-    // PNP_GEMM_VARIANT=1 / 2 / 3 force 256x128 / 256x256 / 128x128 (experiments).
+    // Tile choice (in-kernel clock stamps, PNP_GEMM_STAMPS=1, tools/gemm_stamps.py):
+    //   bf16 ViT-block epilogues (bias -> bf16 | bias+GELU -> bf16 | bias+residual -> f32), >= 128 tiles:
+    //       gemm_nt_wide_kernel, 256 x 256, 32x32x16 MFMA; main loop ~2350 clk per 64-deep slab against
+    //       2048 MFMA clk, epilogue staged through LDS (full-line stores)
+    //   other bf16 with K >= 2048 : generic 256 x 256 (16x16x32 MFMA, simple ring)
+    //   otherwise                 : generic 128 x 128, two workgroups per CU
+    // PNP_GEMM_VARIANT=1 / 2 / 3 / 4 force generic 256x128 / generic 256x256 / generic 128x128 / wide.
     static const int variant = getenv("PNP_GEMM_VARIANT") ? atoi(getenv("PNP_GEMM_VARIANT")) : 0;
     static const int ablate = getenv("PNP_GEMM_ABLATE") ? atoi(getenv("PNP_GEMM_ABLATE")) : 0;
     g.ablate = ablate;
+    static const int want_stamps = getenv("PNP_GEMM_STAMPS") ? atoi(getenv("PNP_GEMM_STAMPS")) : 0;
+    if (want_stamps) {
+        if (!stamp_buf() && hipMalloc(&stamp_buf(), kStampBlocks * 64) != hipSuccess) return PNP_ERR_HIP;
+        g.stamps = stamp_buf();
+    }
     int r;
     const bool big_k = g.K >= 2048 && g.Nvalid >= 512;
-    if (variant == 1) {
+    const int wide = dtype_bf16 ? wide_epilogue_kind(g) : -1;
+    const long tiles256 = (long)((g.M + 255) / 256) * ((g.Nvalid + 255) / 256);
+    if (wide >= 0 && (variant == 4 || (variant == 0 && tiles256 >= 128))) {
+        g.N = (g.Nvalid + 255) / 256 * 256;
+        r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16>(g, s)
+            : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16>(g, s) : launch_wide<WIDE_RESID_F32>(g, s);
+    } else if (variant == 1) {
         r = dtype_bf16 ? launch_big<bf16, 256, 128, 64, 64, 3>(g, s) : launch_big<float, 256, 128, 64, 64, 3>(g, s);
     } else if (dtype_bf16 && (variant == 2 || (variant == 0 && big_k))) {
         g.N = (g.Nvalid + 255) / 256 * 256;
