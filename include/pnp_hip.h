@@ -154,6 +154,12 @@ int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int
 int pnp_op_gemm_ex(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,
                    const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, void* d_out_t,
                    int32_t ldo_t, int32_t mode, void* stream);
+/* The transposed K / V projection form (B/vit.py:93-117 value, B/med.py:201-228 key/value with the image tokens
+ * as output columns): out[m, (n / col_div) * col_pad + n % col_div] = A[m,:] . B[n,:] + bias_rows[m], output in
+ * the compute type; col_div = 0 keeps n. */
+int pnp_op_gemm_tokcols(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,
+                        int32_t K, const float* d_bias_rows, void* d_out_t, int32_t ldo_t, int32_t col_div,
+                        int32_t col_pad, void* stream);
 int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                      float* d_y, void* stream);
 /* Cross-attention over the image tokens as one operator (B/med.py:229-283 forward, its autograd backward):

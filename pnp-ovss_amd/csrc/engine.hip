@@ -1200,6 +1200,15 @@ extern "C" int pnp_op_gemm_ex(int32_t bf, const void* d_A, int32_t lda, const vo
     return gemm_nt(bf, g, (hipStream_t)stream);
 }
 
+extern "C" int pnp_op_gemm_tokcols(int32_t bf, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,
+                                   int32_t K, const float* d_bias_rows, void* d_out_t, int32_t ldo_t, int32_t col_div,
+                                   int32_t col_pad, void* stream) {
+    if (!d_out_t || col_div < 0 || (col_div > 0 && col_pad < col_div)) return PNP_ERR_ARG;
+    GemmArgs g = G_(d_A, lda, d_B, ldb, M, N, K);
+    g.bias = d_bias_rows; g.bias_on_rows = 1; g.out_t = d_out_t; g.ldo_t = ldo_t; g.col_div = col_div; g.col_pad = col_pad;
+    return gemm_nt(bf, g, (hipStream_t)stream);
+}
+
 extern "C" int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                                 float* d_y, void* stream) {
     return layernorm(0, d_x, d_w, d_b, eps, rows, D, d_y, nullptr, nullptr, nullptr, (hipStream_t)stream);

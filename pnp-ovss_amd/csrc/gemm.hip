@@ -366,7 +366,8 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // EPI selects the (compile-time) epilogue: 0 = +bias -> bf16, 1 = +bias, GELU -> bf16, 2 = +bias +residual -> fp32.
-enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2 };
+//   3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (the transposed K / V projections)
+enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3 };
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
@@ -533,6 +534,42 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     __syncthreads();                                    // every wave is done reading the last slab
     constexpr int SROW = 68;                            // floats per staged row (64 + 4 pad)
     float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SROW);
+    if constexpr (EPI == WIDE_TOKCOLS_BF16) {
+        // one output row per store instruction: lane = token column, 128 contiguous bytes per row
+        const int tok = n0 + wn * 64 + lane;
+        const bool tv = tok < g.Nvalid;
+        size_t ocol = tok;
+        if (g.col_div > 0) {
+            const int b = tok / g.col_div;
+            ocol = (size_t)b * g.col_pad + (tok - b * g.col_div);
+        }
+        bf16* const ocolp = reinterpret_cast<bf16*>(g.out_t) + ocol;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int mbase = m0 + wm * 128 + half * 64;
+            float brow = 0.f;                           // lane l holds the bias of row mbase + l
+            if (g.bias && mbase + lane < g.M) brow = g.bias[mbase + lane];
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const f32x16& a = acc[i][half * 2 + jj];
+                        const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(stg + (jj * 32 + l32) * SROW + i * 32 + gq * 8 + hi * 4) = v;
+                    }
+#pragma unroll
+            for (int row = 0; row < 64; row++) {
+                const float v = stg[row * SROW + lane] + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, brow), row));
+                if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo_t] = (bf16)v;
+            }
+        }
+        if (g.ablate == 7) stamp(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);
+        return;
+    }
     const int n = n0 + wn * 64 + (lane & 15) * 4;       // this lane's 4 output columns (same for every row)
     const bool nv = n < g.Nvalid;                       // N is a multiple of 4 on this path
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -584,7 +621,10 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 // the wide kernel's compile-time epilogues cover the ViT block's dense layers; anything else (row / column
 // remaps, per-row bias, stashes, dual outputs) stays on the generic kernels
 static int wide_epilogue_kind(const GemmArgs& g) {
-    if (g.aux || g.row_div || g.col_div || g.bias_on_rows || (g.Nvalid & 3)) return -1;
+    if (g.aux || g.row_div) return -1;
+    if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_t && !g.out_f32 && (g.bias_on_rows || !g.bias) && (g.col_div > 0 || g.bias_on_rows))
+        return WIDE_TOKCOLS_BF16;
+    if (g.col_div || g.bias_on_rows || (g.Nvalid & 3)) return -1;
     if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_t && !g.out_f32) return WIDE_BF16;
     if (g.mode == GEMM_EPI_GELU && !g.resid && g.out_t && !g.out_f32) return WIDE_GELU_BF16;
     if (g.mode == GEMM_EPI_LINEAR && g.resid && g.out_f32 && !g.out_t) return WIDE_RESID_F32;
@@ -800,7 +840,8 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     if (wide >= 0 && (variant == 4 || (variant == 0 && tiles256 >= 128))) {
         g.N = (g.Nvalid + 255) / 256 * 256;
         r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16>(g, s)
-            : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16>(g, s) : launch_wide<WIDE_RESID_F32>(g, s);
+            : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16>(g, s)
+            : wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32>(g, s) : launch_wide<WIDE_TOKCOLS_BF16>(g, s);
     } else if (variant == 1) {
         r = dtype_bf16 ? launch_big<bf16, 256, 128, 64, 64, 3>(g, s) : launch_big<float, 256, 128, 64, 64, 3>(g, s);
     } else if (dtype_bf16 && (variant == 2 || (variant == 0 && big_k))) {

@@ -88,6 +88,61 @@ def test_gemm(bf16, shape):
     assert err < (2e-3 if bf16 else 2e-4) * np.sqrt(K / 128), err      # exact products, fp32 accumulation order only
 
 
+@pytest.mark.parametrize("kind", ["bias_bf16", "gelu_bf16", "resid_f32", "tokcols"])
+@pytest.mark.parametrize("shape", [(4100, 2048, 256), (2200, 3840, 64)])
+def test_gemm_wide_tile_epilogues(kind, shape):
+    """The 256 x 256 bf16 kernel (taken from 128 tiles up) with each of its compile-time epilogues; ragged M,
+    N not a multiple of the tile, K = one slab and several.  Inputs are bf16-exact so only the fp32
+    accumulation order (and, for bf16 outputs, the final rounding: 2^-8 relative) differs from fp64."""
+    from pnp_ovss import hip
+    lib = hip.load_library()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + K)
+    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
+    B = (torch.randn(N, K, generator=g) * 0.25).to(torch.bfloat16).cuda()
+    ref = A.double() @ B.double().t()
+    p = lambda t: t.data_ptr() if t is not None else None
+    if kind == "tokcols":
+        div, pad = 442, 448
+        nimg = (N + div - 1) // div
+        bias = torch.randn(M, generator=g).cuda()
+        out = torch.zeros(M, nimg * pad, device="cuda", dtype=torch.bfloat16)
+        assert lib.pnp_op_gemm_tokcols(1, p(A), K, p(B), K, M, N, K, p(bias), p(out), nimg * pad, div, pad, None) == 0
+        torch.cuda.synchronize()
+        ref = ref + bias.double()[:, None]
+        got = out.double().view(M, nimg, pad)
+        full = torch.zeros(M, nimg * div, dtype=torch.float64, device="cuda")
+        full[:, :N] = ref
+        full = full.view(M, nimg, div)
+        live = torch.zeros(nimg * div, dtype=torch.bool, device="cuda")
+        live[:N] = True
+        live = live.view(nimg, div)
+        err = ((got[:, :, :div] - full).abs() * live).max()
+        assert float(err) <= 2 ** -8 * float(ref.abs().max()) + 1e-3, float(err)
+        assert float(got[:, :, div:].abs().max()) == 0.0                      # pad columns untouched
+        assert float((got[:, :, :div].abs() * (~live)).max()) == 0.0          # columns past N untouched
+        return
+    bias = torch.randn(N, generator=g).cuda()
+    if kind == "resid_f32":
+        resid = torch.randn(M, N, generator=g).cuda()
+        out = resid.clone()                                                    # in place, as the ViT residual stream
+        assert lib.pnp_op_gemm_ex(1, p(A), K, p(B), K, M, N, K, p(bias), p(out), N, p(out), N, None, 0, 0, None) == 0
+        torch.cuda.synchronize()
+        ref = ref + bias.double() + resid.double()
+        err = float((out.double() - ref).abs().max())
+        assert err <= 2e-4 * np.sqrt(K / 64) * max(1.0, float(ref.abs().max()) / 16), err
+        return
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    mode = 1 if kind == "gelu_bf16" else 0
+    assert lib.pnp_op_gemm_ex(1, p(A), K, p(B), K, M, N, K, p(bias), None, 0, None, 0, p(out), N, mode, None) == 0
+    torch.cuda.synchronize()
+    ref = ref + bias.double()
+    if mode:
+        ref = torch.nn.functional.gelu(ref)
+    err = float((out.double() - ref).abs().max())
+    assert err <= 2 ** -8 * float(ref.abs().max()) + 1e-3, err
+
+
 def test_layernorm():
     from pnp_ovss import hip
     lib = hip.load_library()
