@@ -211,7 +211,7 @@ def main():
                                    "BLIP-ITM-large random weights, layer 8 head 9, drop_iter 4, threshold 0.15, "
                                    + ("N-drop" if a.skip_1drop else "1-drop + N-drop") + " blur+CRF",
                        "images_per_step_per_gpu": B, "sharding": "images across ranks, no per-step collective"},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_big_kernel<{a.dtype}> (LDS-DMA ring GEMM; 128x128 tiles for K=1024, 256x256 for K=4096)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": ("gemm_nt_wide_kernel (persistent 256x256 bf16 LDS-DMA ring GEMM, 32x32x16 MFMA; all non-small launches timed)" if a.dtype == "bf16" else "gemm_nt_big_kernel<float> (128x128 fp32 LDS-DMA ring GEMM, 16x16x4 MFMA)"), "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch (rocprofv3 PMC, offline pass)",
                          "launches": launches, "avg_launch_ms": ms / max(launches, 1),

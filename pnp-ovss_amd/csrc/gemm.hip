@@ -348,7 +348,8 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Wide-tile bf16 kernel: 256 x 256 block tile, 8 waves (2 x 4) of 128 x 64, v_mfma_f32_32x32x16_bf16.
+// Wide-tile bf16 kernel: 256 x 256 block tile, 8 waves (2 x 4) of 128 x 64, v_mfma_f32_32x32x16_bf16,
+// PERSISTENT: one workgroup per CU walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
 //
 // Why this shape: one CU takes in at most 64 B/clk of global data (TA / vector L1 path) and every
 // LDS-DMA piece stalls its issuing wave for 60+ cycles, so a 128 x 128 tile (32 KB per 512 MFMA
@@ -363,33 +364,51 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 //   issue DMA of slab t+2 into the slot just vacated || read(s0 of slab t+1) || MFMA(s3)
 // so the MFMAs of s3 (operands already in registers) cover the barrier hand-over, the DMA issue and
 // the first fragment reads of the next slab, and every DMA has a whole slab time to land.
+//
+// Tile hand-over: after the last slab both ring slots are free.  Slot 0 immediately receives slab 0 of
+// the NEXT tile while the accumulators of this tile leave through a staging area that overlays slot 1
+// (clock stamps: a fresh workgroup costs ~3 us of launch gap + 1 us of first-slab latency per tile).
+//
+// Epilogue through LDS: the accumulator layout gives a lane 4 consecutive columns in each of 32
+// different rows, i.e. 16-byte fragments of 32 cache lines per store instruction (measured: as long
+// as the whole K = 1024 main loop).  Each wave transposes one 32-row quarter of its tile at a time
+// (fp32, rows padded by 16 B against bank conflicts) so that 16 consecutive lanes own one 64-column
+// row segment and every global access is a full 128/256-byte line.  vmcnt counts loads and stores in
+// one in-order counter, so a quarter's residual rows are requested BEFORE its first store and no
+// wait ever sits behind a store; epilogues are compile-time variants (no generic branches).
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-// EPI selects the (compile-time) epilogue: 0 = +bias -> bf16, 1 = +bias, GELU -> bf16, 2 = +bias +residual -> fp32.
-//   3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (the transposed K / V projections)
+// EPI: 0 = +bias -> bf16 | 1 = +bias, GELU -> bf16 | 2 = +bias +residual -> fp32 |
+//      3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (transposed K / V projections)
 enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3 };
+constexpr int kWideStageRow = 68;                                  // floats per staged row (64 + 4 pad)
+constexpr int kWideStageBytes = 8 * 32 * kWideStageRow * 4;        // 8 waves x 32 rows
+constexpr int kWideSmem = 65536 + kWideStageBytes;                 // slot 0 | slot 1 overlaid by the staging area
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, ROWB = 128, BK = 64, STAGE = (BM + BN) * ROWB;
     constexpr int TM = 4, TN = 2;                   // 32 x 32 tiles per wave: 128 (m) x 64 (n)
     constexpr int A_DMA = 4, B_DMA = 4, NDMA = 8;   // 8-row pieces per wave per slab
+    constexpr int SROW = kWideStageRow;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l32 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
-
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
-    int bm, bn;
-    tile_coords<4>(blockIdx.x, nbm, nbn, bm, bn);
-    const int m0 = bm * BM, n0 = bn * BN;
-
+    const int ntiles = nbm * nbn;
+    const int nk = g.K / BK;
     const char* Ab = reinterpret_cast<const char*>(g.A);
     const char* Bb = reinterpret_cast<const char*>(g.B);
+
     uint32_t soff[NDMA];
-    {
+    auto set_tile = [&](int tile, int& m0, int& n0) {
+        int bm, bn;
+        tile_coords<4>(tile, nbm, nbn, bm, bn);
+        m0 = bm * BM;
+        n0 = bn * BN;
         const uint32_t lda_b = (uint32_t)g.lda * 2, ldb_b = (uint32_t)g.ldb * 2;
         const int pc = lane & 7;
 #pragma unroll
@@ -406,7 +425,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
             gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
             soff[A_DMA + i] = (uint32_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
         }
-    }
+    };
     auto issue_one = [&](int kt, int i) {
         char* stage = smem + (kt & 1) * STAGE;
         const uint32_t koff = (uint32_t)kt * ROWB;
@@ -415,207 +434,290 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[i] + koff)),
                                          (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
     };
-
-    // lane owns row m = .. + l32 and, per 4-register group gq, columns 8 gq + 4 hi .. + 3 of each 32 x 32
-    // tile (operands are swapped at the MFMA: D = Btile * Atile^T)
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int j = 0; j < TM; j++)
-#pragma unroll
-        for (int i = 0; i < TN; i++)
-#pragma unroll
-            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-
-    // fragment addresses: row = tile row + l32, logical chunk = 2 ks + hi; the swizzle term depends on
-    // l32 only (tile row offsets are multiples of 32), so one XOR per k16 sub-step serves all tiles
-    const int sw = (l32 >> 1) & 7;
-    const int a_row_off = (wm * 128 + l32) * ROWB, b_row_off = BM * ROWB + (wn * 64 + l32) * ROWB;
-    auto read_frags = [&](bf16x8* fa, bf16x8* fb, int kt, int ks) {
-        const char* st = smem + (kt & 1) * STAGE + (((ks * 2 + hi) ^ sw) << 4);
-#pragma unroll
-        for (int j = 0; j < TM; j++) fa[j] = *reinterpret_cast<const bf16x8*>(st + a_row_off + j * 32 * ROWB);
-#pragma unroll
-        for (int i = 0; i < TN; i++) fb[i] = *reinterpret_cast<const bf16x8*>(st + b_row_off + i * 32 * ROWB);
-    };
-    auto mma_all = [&](const bf16x8* fa, const bf16x8* fb) {
-#pragma unroll
-        for (int j = 0; j < TM; j++)
-#pragma unroll
-            for (int i = 0; i < TN; i++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
-    };
-    // interleave hint: one LDS read behind each of the first six MFMAs of a sub-step
-    auto sched_plain = [&]() {
-#pragma unroll
-        for (int u = 0; u < TM + TN; u++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
-    };
-
     auto stamp = [&](int slot) {
         if (g.stamps && tid == 0) {
             g.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
             g.stamps[(size_t)blockIdx.x * 8 + 4 + slot] = wall_clock64();
         }
     };
+
+    // fragment addresses: row = tile row + l32, logical chunk = 2 ks + hi; the swizzle term depends on
+    // l32 only (tile row offsets are multiples of 32), so one XOR per k16 sub-step serves all tiles
+    const int sw = (l32 >> 1) & 7;
+    const int a_row_off = (wm * 128 + l32) * ROWB, b_row_off = BM * ROWB + (wn * 64 + l32) * ROWB;
+    float* const stg = reinterpret_cast<float*>(smem + 65536) + wave * (32 * SROW);
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int m0, n0;
     stamp(0);
-    const int nk = g.K / BK;
+    if (g.ablate >= 100) {          // experiment (no gain measured): de-phase workgroups so epilogue bursts do not coincide
+        const int steps = ((blockIdx.x >> 3) & 7) * (g.ablate - 100);
+        for (int i = 0; i < steps; i++) __builtin_amdgcn_s_sleep(8);
+    }
+    set_tile(tile, m0, n0);
 #pragma unroll
     for (int i = 0; i < NDMA; i++) issue_one(0, i);
-    PNP_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
-    stamp(1);
-    if (nk > 1) {
-#pragma unroll
-        for (int i = 0; i < NDMA; i++) issue_one(1, i);
-    }
-    bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-    read_frags(fa0, fb0, 0, 0);
-    // sub-steps s0..s2 of slab kt: MFMAs on one fragment set, reads of the next sub-step into the other
-    auto body012 = [&](int kt) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        read_frags(fa1, fb1, kt, 1);
-        mma_all(fa0, fb0);
-        sched_plain();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        read_frags(fa0, fb0, kt, 2);
-        mma_all(fa1, fb1);
-        sched_plain();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        read_frags(fa1, fb1, kt, 3);
-        mma_all(fa0, fb0);
-        sched_plain();
-    };
-    int kt = 0;
-    for (; kt + 2 < nk; kt++) {                 // steady state: slab kt+2 exists
-        body012(kt);
-        PNP_WAIT_VM_LGKM(0);                    // own s3 fragments in registers, own pieces of slab kt+1 landed
-        __builtin_amdgcn_s_barrier();           // slab kt+1 complete; nobody reads slab kt's slot any more
-        read_frags(fa0, fb0, kt + 1, 0);
-#pragma unroll
-        for (int i = 0; i < NDMA; i++) issue_one(kt + 2, i);
-        mma_all(fa1, fb1);
-        // LDS-DMA writes may not be reordered against the LDS reads: reads lead, DMA pieces follow
-#pragma unroll
-        for (int u = 0; u < 3; u++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    }
-    if (kt + 1 < nk) {                          // second-to-last slab: nothing left to fetch
-        body012(kt);
-        PNP_WAIT_VM_LGKM(0);
-        __builtin_amdgcn_s_barrier();
-        read_frags(fa0, fb0, kt + 1, 0);
-        mma_all(fa1, fb1);
-        sched_plain();
-        kt++;
-    }
-    body012(kt);                                // last slab
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    mma_all(fa1, fb1);
-    stamp(2);
 
-    // Epilogue through LDS: the accumulator layout gives a lane 4 consecutive columns in each of 32
-    // different rows, i.e. 16-byte fragments of 32 cache lines per store instruction.  Each wave
-    // transposes its tile (two 64-row halves, fp32, rows padded by 16 B against bank conflicts)
-    // so that 16 consecutive lanes own one 64-column row segment: every global access of the
-    // epilogue is then a full 128/256-byte line.  vmcnt counts loads and stores in one in-order
-    // counter, so the residual rows of a half are all requested BEFORE its first store and no wait
-    // ever sits behind a store; the epilogue is specialised at compile time (no generic branches).
-    __syncthreads();                                    // every wave is done reading the last slab
-    constexpr int SROW = 68;                            // floats per staged row (64 + 4 pad)
-    float* stg = reinterpret_cast<float*>(smem) + wave * (64 * SROW);
-    if constexpr (EPI == WIDE_TOKCOLS_BF16) {
-        // one output row per store instruction: lane = token column, 128 contiguous bytes per row
-        const int tok = n0 + wn * 64 + lane;
-        const bool tv = tok < g.Nvalid;
-        size_t ocol = tok;
-        if (g.col_div > 0) {
-            const int b = tok / g.col_div;
-            ocol = (size_t)b * g.col_pad + (tok - b * g.col_div);
-        }
-        bf16* const ocolp = reinterpret_cast<bf16*>(g.out_t) + ocol;
+    for (;;) {
+        // lane owns row m = .. + l32 and, per 4-register group gq, columns 8 gq + 4 hi .. + 3 of each 32 x 32
+        // tile (operands are swapped at the MFMA: D = Btile * Atile^T)
+        f32x16 acc[TN][TM];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int mbase = m0 + wm * 128 + half * 64;
-            float brow = 0.f;                           // lane l holds the bias of row mbase + l
-            if (g.bias && mbase + lane < g.M) brow = g.bias[mbase + lane];
+        for (int j = 0; j < TM; j++)
 #pragma unroll
-            for (int jj = 0; jj < 2; jj++)
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+        auto read_frags = [&](bf16x8* fa, bf16x8* fb, int kt, int ks) {
+            const char* st = smem + (kt & 1) * STAGE + (((ks * 2 + hi) ^ sw) << 4);
+#pragma unroll
+            for (int j = 0; j < TM; j++) fa[j] = *reinterpret_cast<const bf16x8*>(st + a_row_off + j * 32 * ROWB);
+#pragma unroll
+            for (int i = 0; i < TN; i++) fb[i] = *reinterpret_cast<const bf16x8*>(st + b_row_off + i * 32 * ROWB);
+        };
+        auto mma_all = [&](const bf16x8* fa, const bf16x8* fb) {
+#pragma unroll
+            for (int j = 0; j < TM; j++)
 #pragma unroll
                 for (int i = 0; i < TN; i++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+        };
+        // interleave hint: one LDS read behind each of the first six MFMAs of a sub-step
+        auto sched_plain = [&]() {
 #pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        const f32x16& a = acc[i][half * 2 + jj];
-                        const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(stg + (jj * 32 + l32) * SROW + i * 32 + gq * 8 + hi * 4) = v;
-                    }
-#pragma unroll
-            for (int row = 0; row < 64; row++) {
-                const float v = stg[row * SROW + lane] + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, brow), row));
-                if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo_t] = (bf16)v;
+            for (int u = 0; u < TM + TN; u++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
+        };
+
+        // slab 0 of this tile is in flight (issued before the previous tile's epilogue, or above)
+        PNP_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();               // slab 0 complete; staging area (slot 1) no longer read
+        if (nk > 1) {
+#pragma unroll
+            for (int i = 0; i < NDMA; i++) issue_one(1, i);
         }
-        if (g.ablate == 7) stamp(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        stamp(3);
-        return;
-    }
-    const int n = n0 + wn * 64 + (lane & 15) * 4;       // this lane's 4 output columns (same for every row)
-    const bool nv = n < g.Nvalid;                       // N is a multiple of 4 on this path
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+        bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        read_frags(fa0, fb0, 0, 0);
+        // sub-steps s0..s2 of slab kt: MFMAs on one fragment set, reads of the next sub-step into the other
+        auto body012 = [&](int kt) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            read_frags(fa1, fb1, kt, 1);
+            mma_all(fa0, fb0);
+            sched_plain();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            read_frags(fa0, fb0, kt, 2);
+            mma_all(fa1, fb1);
+            sched_plain();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            read_frags(fa1, fb1, kt, 3);
+            mma_all(fa0, fb0);
+            sched_plain();
+        };
+        int kt = 0;
+        for (; kt + 2 < nk; kt++) {                 // steady state: slab kt+2 exists
+            body012(kt);
+            PNP_WAIT_VM_LGKM(0);                    // own s3 fragments in registers, own pieces of slab kt+1 landed
+            __builtin_amdgcn_s_barrier();           // slab kt+1 complete; nobody reads slab kt's slot any more
+            read_frags(fa0, fb0, kt + 1, 0);
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const int mrow0 = m0 + wm * 128 + half * 64 + (lane >> 4);
-        f32x4 rv[16];
-        if constexpr (EPI == WIDE_RESID_F32) {
+            for (int i = 0; i < NDMA; i++) issue_one(kt + 2, i);
+            mma_all(fa1, fb1);
+            // LDS-DMA writes may not be reordered against the LDS reads: reads lead, DMA pieces follow
 #pragma unroll
-            for (int it = 0; it < 16; it++) {
-                const int m = mrow0 + it * 4;
-                rv[it] = (m < g.M && nv) ? *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n) : bv;
+            for (int u = 0; u < 3; u++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             }
-        }
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++)
+            for (int u = 0; u < 4; u++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        if (kt + 1 < nk) {                          // second-to-last slab: nothing left to fetch
+            body012(kt);
+            PNP_WAIT_VM_LGKM(0);
+            __builtin_amdgcn_s_barrier();
+            read_frags(fa0, fb0, kt + 1, 0);
+            mma_all(fa1, fb1);
+            sched_plain();
+            kt++;
+        }
+        body012(kt);                                // last slab
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        mma_all(fa1, fb1);
+        if (tile == (int)blockIdx.x) stamp(2);
+
+        __syncthreads();                            // every wave is done reading the last slab: both slots are free
+        if (g.ablate == 30 && tile == (int)blockIdx.x) stamp(1);
+        const int em0 = m0, en0 = n0;
+        // epilogue operands are requested BEFORE the next tile's first slab: vmcnt is one in-order counter, a
+        // wait for a load issued behind the DMA pieces would also wait for those (HBM latency, ~2 us)
+        const int n = en0 + wn * 64 + (lane & 15) * 4;          // this lane's 4 output columns (same for every row)
+        const bool nv = n < g.Nvalid;                           // N is a multiple of 4 on the row-major epilogues
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        f32x4 rv[8];
+        f32x4 bacc[TN][4];                          // bf16 epilogues: bias in the accumulator layout
+        if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16) {
 #pragma unroll
             for (int i = 0; i < TN; i++)
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++) {
-                    const f32x16& a = acc[i][half * 2 + jj];
-                    const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
-                    *reinterpret_cast<f32x4*>(stg + (jj * 32 + l32) * SROW + i * 32 + gq * 8 + hi * 4) = v;
+                    const int nn = en0 + wn * 64 + i * 32 + gq * 8 + hi * 4;
+                    bacc[i][gq] = (g.bias && nn < g.Nvalid) ? *reinterpret_cast<const f32x4*>(g.bias + nn) : bv;
                 }
+        }
+        if constexpr (EPI == WIDE_RESID_F32) {
+            if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+            {
+                const int mrow0 = em0 + wm * 128 + (lane >> 4);
 #pragma unroll
-        for (int it = 0; it < 16; it++) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 4);
-            const int m = mrow0 + it * 4;
-            v += bv;
-            if constexpr (EPI == WIDE_GELU_BF16) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = gelu_erf_fast(v[e]);
-            }
-            if constexpr (EPI == WIDE_RESID_F32) {
-                v += rv[it];
-                if (m < g.M && nv) *reinterpret_cast<f32x4*>(g.out_f32 + (size_t)m * g.ldo + n) = v;
-            } else {
-                const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-                if (m < g.M && nv) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16*>(g.out_t) + (size_t)m * g.ldo_t + n) = pk;
+                for (int it = 0; it < 8; it++) {
+                    const int m = mrow0 + it * 4;
+                    rv[it] = (m < g.M && nv) ? *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n) : bv;
+                }
             }
         }
+        float brow0 = 0.f;
+        if constexpr (EPI == WIDE_TOKCOLS_BF16) {
+            const int mbase = em0 + wm * 128;
+            if (g.bias && l32 == lane && mbase + lane < g.M) brow0 = g.bias[mbase + lane];
+        }
+        const int next = tile + gridDim.x;
+        if (next < ntiles) {                        // slab 0 of the next tile flies during this tile's epilogue
+            set_tile(next, m0, n0);
+#pragma unroll
+            for (int i = 0; i < NDMA; i++) issue_one(0, i);
+        }
+        if (g.ablate == 31 && tile == (int)blockIdx.x) stamp(1);
+
+        if constexpr (EPI == WIDE_TOKCOLS_BF16) {
+            // one output row per store instruction: lane = token column, 128 contiguous bytes per row
+            const int tok = en0 + wn * 64 + lane;
+            const bool tv = tok < g.Nvalid;
+            size_t ocol = tok;
+            if (g.col_div > 0) {
+                const int b = tok / g.col_div;
+                ocol = (size_t)b * g.col_pad + (tok - b * g.col_div);
+            }
+            bf16* const ocolp = reinterpret_cast<bf16*>(g.out_t) + ocol;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const int mbase = em0 + wm * 128 + qd * 32;
+                float brow = brow0;                 // lane l holds the bias of row mbase + l
+                if (qd > 0 && g.bias && l32 == lane && mbase + lane < g.M) brow = g.bias[mbase + lane];
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const f32x16& a = acc[i][qd];
+                        const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(stg + l32 * SROW + i * 32 + gq * 8 + hi * 4) = v;
+                    }
+#pragma unroll
+                for (int row = 0; row < 32; row++) {
+                    const float v = stg[row * SROW + lane] +
+                                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, brow), row));
+                    if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo_t] = (bf16)v;
+                }
+            }
+        } else if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16) {
+            // bias (+GELU) and the bf16 rounding happen in the accumulator layout; the tile is staged as bf16
+            // (half the LDS bytes: LDS stores run at ~80 B/clk/CU) in two 64-row halves, 136-byte rows so the
+            // 8-byte stores of 16 lanes (16 rows, same column) fall in 16 different bank pairs
+            constexpr int HROW = 68;                // bf16 per staged row (64 + 4 pad)
+            bf16* const stgh = reinterpret_cast<bf16*>(smem + 65536) + wave * (64 * HROW);
+            const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+            bf16* const obase = reinterpret_cast<bf16*>(g.out_t) + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo_t + n;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                    for (int i = 0; i < TN; i++)
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++) {
+                            const f32x16& a = acc[i][half * 2 + jj];
+                            f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
+                            v += bacc[i][gq];
+                            if constexpr (EPI == WIDE_GELU_BF16) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) v[e] = gelu_logistic_fit(v[e]);
+                            }
+                            const bf16x4 pk = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+                            *reinterpret_cast<bf16x4*>(stgh + (jj * 32 + l32) * HROW + i * 32 + gq * 8 + hi * 4) = pk;
+                        }
+                bf16x4 sv[16];                      // all LDS reads of the half in flight before the first store
+#pragma unroll
+                for (int it = 0; it < 16; it++)
+                    sv[it] = *reinterpret_cast<const bf16x4*>(stgh + (it * 4 + (lane >> 4)) * HROW + (lane & 15) * 4);
+                if (full) {
+#pragma unroll
+                    for (int it = 0; it < 16; it++)
+                        *reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t) = sv[it];
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 16; it++) {
+                        const int m = em0 + wm * 128 + half * 64 + it * 4 + (lane >> 4);
+                        if (m < g.M && nv) *reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t) = sv[it];
+                    }
+                }
+                if (g.ablate == 32 + half && tile == (int)blockIdx.x) stamp(1);
+            }
+        } else {
+            // fp32 residual epilogue, 32-row quarters staged as fp32.  The residual rows of quarter q+1 are
+            // requested before the stores of quarter q (two register sets), so each wait has a whole quarter
+            // of work in front of it and never sits behind a store.
+            const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+            const float* const rbase = g.resid + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldr + n;
+            float* const obase = g.out_f32 + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo + n;
+            f32x4 rw[8];
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                f32x4* const rcur = (qd & 1) ? rw : rv;
+                f32x4* const rnxt = (qd & 1) ? rv : rw;
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const f32x16& a = acc[i][qd];
+                        const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(stg + l32 * SROW + i * 32 + gq * 8 + hi * 4) = v;
+                    }
+                if (qd < 3) {
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const int m = em0 + wm * 128 + (qd + 1) * 32 + it * 4 + (lane >> 4);
+                        rnxt[it] = (full || (m < g.M && nv)) ? *reinterpret_cast<const f32x4*>(rbase + (size_t)((qd + 1) * 32 + it * 4) * g.ldr) : bv;
+                    }
+                }
+                f32x4 sv[8];                        // all LDS reads of the quarter in flight before the first use
+#pragma unroll
+                for (int it = 0; it < 8; it++)
+                    sv[it] = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 4);
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const f32x4 v = sv[it] + bv + rcur[it];
+                    const int m = em0 + wm * 128 + qd * 32 + it * 4 + (lane >> 4);
+                    if (full || (m < g.M && nv)) *reinterpret_cast<f32x4*>(obase + (size_t)(qd * 32 + it * 4) * g.ldo) = v;
+                }
+                if (g.ablate == 32 + qd && tile == (int)blockIdx.x) stamp(1);
+            }
+        }
+        if (g.ablate < 30 && tile == (int)blockIdx.x) stamp(1);       // diagnostics: first tile's stores issued
+        if (next >= ntiles) break;
+        tile = next;
     }
-    if (g.ablate == 7) stamp(1);                        // diagnostics: stores issued, not yet acknowledged
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamp(3);
+    if (g.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);                                   // whole workgroup (all its tiles) done
+    }
 }
 
 // the wide kernel's compile-time epilogues cover the ViT block's dense layers; anything else (row / column
@@ -634,15 +736,24 @@ static int wide_epilogue_kind(const GemmArgs& g) {
 template <int EPI>
 static int launch_wide(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
-    const size_t smem = 8 * 64 * 68 * 4;    // 136 KB: the 2-slot ring (128 KB) or the staged epilogue
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return PNP_ERR_HIP;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    static const int persist = getenv("PNP_GEMM_PERSIST") ? atoi(getenv("PNP_GEMM_PERSIST")) : 1;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
+                                kWideSmem) != hipSuccess)
             return PNP_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt_wide_kernel<EPI>, dim3(nbm * nbn), dim3(512), smem, s, g);
+    const int ntiles = nbm * nbn;
+    const int grid = (persist && ntiles > n_cu) ? n_cu : ntiles;      // one workgroup per CU (LDS-limited) walks the tiles
+    hipLaunchKernelGGL(gemm_nt_wide_kernel<EPI>, dim3(grid), dim3(512), kWideSmem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 

@@ -17,6 +17,7 @@ def run(M, N, K, bias, resid, f32out, tout, mode, tag):
     for _ in range(3): assert call() == 0
     torch.cuda.synchronize()
     nb = ((M + 255) // 256) * ((N + 255) // 256)
+    if os.environ.get("PNP_GEMM_PERSIST", "1") != "0" and int(os.environ.get("TILE", "256")) == 256: nb = min(nb, 256)
     st = np.zeros((nb, 8), dtype=np.uint64)
     assert lib.pnp_dbg_gemm_stamps(st.ctypes.data, nb) == 0
     cyc = st[:, :4].astype(np.int64); wall = st[:, 4:].astype(np.int64)
@@ -29,8 +30,9 @@ def run(M, N, K, bias, resid, f32out, tout, mode, tag):
     print(f"{tag}: M={M} N={N} K={K} blocks={nb}  kernel span {us[:, 3].max():.1f} us; clock {np.median(ghz):.2f} GHz")
     print(f"  per block median us: prologue {np.median(d[:,0]):.2f}  main {np.median(d[:,1]):.2f} ({np.median(d[:,1])/nk:.3f}/slab = {np.median(dc[:,1])/nk:.0f} clk)  epilogue {np.median(d[:,2]):.2f}")
     order = np.argsort(us[:, 0])
-    if os.environ.get("PNP_GEMM_ABLATE") == "7":
-        print(f"  epilogue split: stage+issue {np.median(us[:,1]-us[:,2]):.2f} us, drain {np.median(us[:,3]-us[:,1]):.2f} us")
+    print(f"  first tile: main loop ends {np.median(us[:,2]-us[:,0]):.2f}, epilogue (stage + issue) {np.median(us[:,1]-us[:,2]):.2f} us")
+    ntile_all = ((M + 255) // 256) * ((N + 255) // 256)
+    print(f"  persistent: tiles/block {ntile_all / nb:.2f}; block total median {np.median(us[:,3]-us[:,0]):.1f} us, max {np.max(us[:,3]-us[:,0]):.1f}; first tile main-end at {np.median(us[:,2]-us[:,0]):.1f}")
     print("  start times (us) quantiles", np.round(np.quantile(us[:, 0], [0, .25, .5, .75, 1]), 1), " end", np.round(np.quantile(us[:, 3], [0, .25, .5, .75, 1]), 1))
 M = 15470
 run(M, 3072, 1024, True, False, False, True, 0, "qkv")
