@@ -608,6 +608,7 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
         {   // V^T: [D, B*Npad] = Wv . xn^T, token columns padded per image
             GemmArgs g = G_((const char*)w.qkv_w + (size_t)2 * D * D * e->esz, D, e->xn, D, D, M, D);
             g.bias = w.qkv_b + 2 * D; g.bias_on_rows = 1; g.out_t = e->vt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
+            g.col_perm16 = bf ? 1 : 0;        // the bf16 attention kernel reads V^T in accumulator order
             KCHK(e, gemm_nt(bf, g, s));
         }
         KCHK(e, vit_attention(bf, e->qk, 2 * D, D, e->vt, ldv, e->Npad, e->ctx, B, e->c.vit_heads, N, scale, s));

@@ -2,6 +2,8 @@
 // LayerNorm, and the fused patch self-attention (flash-style, MFMA QK^T / PV, LDS-staged K / V^T).
 // Reference: vit.py:274-290 (forward), :91-121 (Attention), :164-167 (Block);
 //            PnP_OVSS_0514_updated_segmentation.py:597-603 (zeroing dropped 16x16 blocks).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -106,7 +108,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // lane column) -> online softmax entirely per lane -> O^T += V^T.P^T with P taken straight from
 // the S^T accumulators.  N x N scores are never materialised (the reference does: vit.py:106-108).
 //   qk : [B*N, ld_qk]  (q of head h at column h*64, k at column D + h*64)
-//   vt : [D, ld_vt]    row h*64+d, column b*Npad + key   (V^T written by the transposed-V GEMM)
+//   vt : [D, ld_vt]    row h*64+d, column b*Npad + key   (V^T written by the transposed-V GEMM; fp32 mode only:
+//                      the bf16 engine uses vit_attn32_kernel below)
 //   ctx: [B*N, D]
 template <typename T>
 __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qk, int ld_qk, int D,
@@ -234,6 +237,156 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qk,
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 ViT self-attention, second generation.  One wave = 32 queries of one (image, head) with
+// v_mfma_f32_32x32x16_bf16; a workgroup is up to 8 such waves sharing the K / V^T tiles, which arrive by
+// LDS-DMA into a two-slot ring (one s_barrier per 64-key tile).  Against the first kernel (16 queries
+// per wave, 16x16 tiles, register-staged tiles) this halves the LDS fragment bytes per FLOP and per
+// score element spends one fma + one exp2 + one add + half a max3 + half a cvt:
+//   S^T = K.Q^T (keys on accumulator rows, the query on the lane column) -> running max per lane pair
+//   -> p = exp2(s c - m c), c = scale log2 e -> O^T += V^T.P^T with P taken from the S^T registers in
+//   "accumulator order" (the V^T fragment is read with the same key permutation).
+// The O rescale is skipped when no lane of the wave raised its maximum.
+__global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict__ qk, int ld_qk, int D,
+                                                         const bf16* __restrict__ vt, int ld_vt, int Npad,
+                                                         bf16* __restrict__ ctx, int N, float scale, int nqw) {
+    constexpr int ROWB = 128, TILE = 64 * ROWB;         // K tile [64 keys][64 d], V^T tile [64 d][64 keys]
+    __shared__ __attribute__((aligned(16))) char ring[2][2 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const size_t row0 = (size_t)b * N;
+    const int qw = blockIdx.x * nwaves + wave;           // this wave's 32-query group
+    int qrow = qw * 32 + l32;
+    const bool q_valid = qw < nqw && qrow < N;
+    qrow = qrow < N ? qrow : N - 1;
+
+    bf16x8 fq[4];                                       // Q as the B operand: lane = query, 8 d per k16 step
+    {
+        const bf16* qp = qk + (row0 + qrow) * ld_qk + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) fq[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+
+    // DMA: 16 pieces of 8 rows per tile pair (8 K + 8 V^T), dealt round-robin to the waves
+    const char* kbase = reinterpret_cast<const char*>(qk + row0 * ld_qk + D + h * 64);
+    const char* vbase = reinterpret_cast<const char*>(vt + (size_t)(h * 64) * ld_vt + (size_t)b * Npad);
+    const int prow = lane >> 3, pc = lane & 7;
+    auto issue_tile = [&](int t) {
+        char* dst = ring[t & 1];
+        for (int p = wave; p < 16; p += nwaves) {
+            const int row = (p & 7) * 8 + prow;
+            const int sc = pc ^ ((row >> 1) & 7);
+            const char* src;
+            if (p < 8) {
+                int key = t * 64 + row;
+                key = key < N ? key : N - 1;
+                src = kbase + (size_t)key * ld_qk * 2 + sc * 16;
+            } else {
+                src = vbase + (size_t)row * ld_vt * 2 + (size_t)t * 128 + sc * 16;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;               // l_run: this lane's share of the row sum
+    const float c = scale * 1.4426950408889634f;
+    const int sw = (l32 >> 1) & 7;
+    const int ntiles = (N + 63) / 64;
+
+    issue_tile(0);
+    for (int t = 0; t < ntiles; t++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // tile t landed; nobody reads the other slot any more
+        if (t + 1 < ntiles) issue_tile(t + 1);
+        const char* Ks = ring[t & 1];
+        const char* Vs = Ks + TILE;
+
+        // all fragment reads of the tile up front: the V^T reads land while the softmax runs
+        bf16x8 fk[2][4];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                fk[kt][ks] = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + l32) * ROWB + (((ks * 2 + hi) ^ sw) << 4));
+        f32x16 s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[kt][0], fq[0], zero16, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 4; ks++) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fk[kt][ks], fq[ks], s[kt], 0, 0, 0);
+        }
+        if (t == ntiles - 1 && (N & 63)) {              // ragged last tile: keys >= N never win
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int key = t * 64 + kt * 32 + (e >> 2) * 8 + hi * 4 + (e & 3);
+                    if (key >= N) s[kt][e] = -INFINITY;
+                }
+        }
+        float mx;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(s[0][0]), "v"(s[0][1]), "v"(s[0][2]));
+#pragma unroll
+        for (int e = 3; e + 1 < 16; e += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][e]), "v"(s[0][e + 1]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[0][15]), "v"(s[1][0]));
+#pragma unroll
+        for (int e = 1; e + 1 < 16; e += 2) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][e]), "v"(s[1][e + 1]));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(mx), "v"(s[1][15]), "v"(m_run));
+        const float m_new = fmaxf(mx, __shfl_xor(mx, 32, 64));     // both halves of this query's keys (and the running max)
+        {   // unconditional rescale: a branch around it makes the compiler shuttle the 32 O registers through copies
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int i = 0; i < 2; i++) o[i] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+        const float mc = -m_run * c;
+        bf16x8 fp[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][e], c, mc));
+                l_run += p;
+                fp[kt * 2 + (e >> 3)][e & 7] = (bf16)p;
+            }
+        // O^T += V^T . P^T : k16 step j covers keys 16j .. 16j+15, lane half hi holds keys 16j + 4hi + (0..3) and
+        // 16j + 8 + 4hi + (0..3) (accumulator order)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) {
+                // V^T arrives with the two middle 4-token groups of every 16 swapped (GEMM epilogue, col_perm16), so
+                // the 8 keys of lane half hi are one 16-byte chunk
+                const bf16x8 fv = *reinterpret_cast<const bf16x8*>(Vs + (dt * 32 + l32) * ROWB + (((2 * j + hi) ^ sw) << 4));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp[j], o[dt], 0, 0, 0);
+            }
+    }
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q_valid) {
+        const float inv = 1.0f / l_run;
+        bf16* op = ctx + (row0 + qrow) * D + h * 64 + hi * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const bf16x4 pk = {(bf16)(o[dt][g4 * 4] * inv), (bf16)(o[dt][g4 * 4 + 1] * inv), (bf16)(o[dt][g4 * 4 + 2] * inv),
+                                   (bf16)(o[dt][g4 * 4 + 3] * inv)};
+                *reinterpret_cast<bf16x4*>(op + dt * 32 + g4 * 8) = pk;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 template <typename T>
 static int vit_attn_t(const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
@@ -247,6 +400,13 @@ static int vit_attn_t(const void* qk, int ld_qk, int D, const void* vt, int ld_v
 int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
                   int H, int N, float scale, hipStream_t s) {
     if (D != H * 64 || Npad % 64 || Npad < N) return PNP_ERR_ARG;
+    if (bf) {       // vt must come from the GEMM's col_perm16 epilogue (middle 4-token groups of every 16 swapped)
+        const int nqw = (N + 31) / 32;                          // 32-query waves per (image, head)
+        const int nblk = (nqw + 7) / 8, wpb = (nqw + nblk - 1) / nblk;
+        hipLaunchKernelGGL(vit_attn32_kernel, dim3(nblk, H, B), dim3(wpb * 64), 0, s, (const bf16*)qk, ld_qk, D,
+                           (const bf16*)vt, ld_vt, Npad, (bf16*)ctx, N, scale, nqw);
+        return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+    }
     return bf ? vit_attn_t<bf16>(qk, ld_qk, D, vt, ld_vt, Npad, ctx, B, H, N, scale, s)
               : vit_attn_t<float>(qk, ld_qk, D, vt, ld_vt, Npad, ctx, B, H, N, scale, s);
 }
