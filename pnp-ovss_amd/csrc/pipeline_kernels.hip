@@ -352,7 +352,21 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
             const int rows = TH + 2 * radius;            // xs[rows][TW]
             const int c = tid & 63;
             const int x = x0 + c < W ? x0 + c : W - 1;
-            for (int r = tid >> 6; r < rows; r += 4) xs[r * TW + c] = src[(size_t)reflect_fast(y0 - radius + r, H) * W + x];
+            // eight independent loads in flight per thread (a one-load-per-iteration loop made the whole kernel
+            // wait on global latency: the arithmetic of a tile is ~1 us, its staging was ~20 us)
+            for (int r0 = tid >> 6; r0 < rows; r0 += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int r = r0 + 4 * u;
+                    v[u] = r < rows ? src[(size_t)reflect_fast(y0 - radius + r, H) * W + x] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int r = r0 + 4 * u;
+                    if (r < rows) xs[r * TW + c] = v[u];
+                }
+            }
             __syncthreads();
             const int rg = tid >> 6;
             blur_window8(xs + (size_t)(rg * 8 + radius) * TW + c, TW, wl, radius, acc);
@@ -362,10 +376,22 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
                     if (y0 + rg * 8 + i < H) dst[(size_t)(y0 + rg * 8 + i) * W + x0 + c] = (float)acc[i];
             }
         } else {
-            for (int r = 0; r < TH; r++) {
-                const int y = y0 + r < H ? y0 + r : H - 1;
-                const float* srow = src + (size_t)y * W;
-                for (int c = tid; c < colsP; c += 256) xs[r * colsP + c] = srow[reflect_fast(x0 - radius + c, W)];
+            // flat (row, column) index so all 256 threads load, eight independent loads in flight each
+            const int total = TH * colsP;
+            for (int i0 = tid; i0 < total; i0 += 8 * 256) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * 256;
+                    const int r = i / colsP, c = i - r * colsP;
+                    const int y = y0 + r < H ? y0 + r : H - 1;
+                    v[u] = i < total ? src[(size_t)y * W + reflect_fast(x0 - radius + c, W)] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * 256;
+                    if (i < total) xs[i] = v[u];
+                }
             }
             __syncthreads();
             const int rr = tid & 31, cg = tid >> 5;

@@ -402,7 +402,8 @@ int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int 
     if (D != H * 64 || Npad % 64 || Npad < N) return PNP_ERR_ARG;
     if (bf) {       // vt must come from the GEMM's col_perm16 epilogue (middle 4-token groups of every 16 swapped)
         const int nqw = (N + 31) / 32;                          // 32-query waves per (image, head)
-        const int nblk = (nqw + 7) / 8, wpb = (nqw + nblk - 1) / nblk;
+        static const int max_wpb = getenv("PNP_ATTN_WPB") ? atoi(getenv("PNP_ATTN_WPB")) : 8;
+        const int nblk = (nqw + max_wpb - 1) / max_wpb, wpb = (nqw + nblk - 1) / nblk;
         hipLaunchKernelGGL(vit_attn32_kernel, dim3(nblk, H, B), dim3(wpb * 64), 0, s, (const bf16*)qk, ld_qk, D,
                            (const bf16*)vt, ld_vt, Npad, (bf16*)ctx, N, scale, nqw);
         return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
