@@ -345,33 +345,45 @@ __global__ __launch_bounds__(256) void crf_splat4_kernel(const CrfLattice L, con
     }
 }
 
-// one axis of the lattice blur: new = old + 0.5 * (n1 + n2), absent neighbours contribute 0
+// one axis of the lattice blur: new = old + 0.5 * (n1 + n2), absent neighbours contribute 0.
+// Work items are (lattice point, 16-byte channel chunk) pairs in linear order, so a wave touches 1 KB of
+// consecutive value bytes whatever Kp is (no idle lanes at Kp = 24), and every thread keeps two items -- six
+// independent value gathers behind four index loads -- in flight.  (The same item order made the splat
+// slower: its lanes then diverge on the contributor counts of more points per wave.)
 __global__ __launch_bounds__(256) void crf_blur4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
                                                         const float* __restrict__ src, float* __restrict__ dst, int axis,
                                                         int img0, int nimg) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int c0 = threadIdx.x & 7, pl = threadIdx.x >> 3;
     const int* n1 = L.n1 + (size_t)axis * L.cap;
     const int* n2 = L.n2 + (size_t)axis * L.cap;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
         const PostDesc im = imgs[b];
         const int K4 = im.Kp >> 2;
         const int lo = L.idbase[b], hi = L.idbase[b + 1];
         const f32x4* S4 = reinterpret_cast<const f32x4*>(src + im.voff[L.which]);
         f32x4* D4 = reinterpret_cast<f32x4*>(dst + im.voff[L.which]);
-        for (int idl = slot * 32 + pl; idl < hi - lo; idl += bpx * 32) {
-            const int a = n1[lo + idl], d = n2[lo + idl];
-            for (int c = c0; c < K4; c += 8) {
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 va = a >= 0 ? S4[(size_t)(a - lo) * K4 + c] : zero;
-                const f32x4 vd = d >= 0 ? S4[(size_t)(d - lo) * K4 + c] : zero;
-                const f32x4 old = S4[(size_t)idl * K4 + c];
-                f32x4 o;
+        const int nitem = (hi - lo) * K4, stride = bpx * 256;
+        for (int it0 = slot * 256 + threadIdx.x; it0 < nitem; it0 += 2 * stride) {
+            const int it1 = it0 + stride;
+            const bool two = it1 < nitem;
+            const int p0 = it0 / K4, p1 = two ? it1 / K4 : p0;
+            const int a0 = n1[lo + p0], d0 = n2[lo + p0], a1 = n1[lo + p1], d1 = n2[lo + p1];
+            const int c0 = it0 - p0 * K4, c1 = (two ? it1 : it0) - p1 * K4;
+            const f32x4 va0 = a0 >= 0 ? S4[(size_t)(a0 - lo) * K4 + c0] : zero;
+            const f32x4 vd0 = d0 >= 0 ? S4[(size_t)(d0 - lo) * K4 + c0] : zero;
+            const f32x4 old0 = S4[it0];
+            const f32x4 va1 = a1 >= 0 ? S4[(size_t)(a1 - lo) * K4 + c1] : zero;
+            const f32x4 vd1 = d1 >= 0 ? S4[(size_t)(d1 - lo) * K4 + c1] : zero;
+            const f32x4 old1 = S4[two ? it1 : it0];
+            f32x4 o0, o1;
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    o[i] = (float)__dadd_rn((double)old[i], __dmul_rn(0.5, (double)__fadd_rn(va[i], vd[i])));
-                D4[(size_t)idl * K4 + c] = o;
+            for (int i = 0; i < 4; i++) {
+                o0[i] = (float)__dadd_rn((double)old0[i], __dmul_rn(0.5, (double)__fadd_rn(va0[i], vd0[i])));
+                o1[i] = (float)__dadd_rn((double)old1[i], __dmul_rn(0.5, (double)__fadd_rn(va1[i], vd1[i])));
             }
+            D4[it0] = o0;
+            if (two) D4[it1] = o1;
         }
     }
 }
