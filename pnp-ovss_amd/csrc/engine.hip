@@ -1210,6 +1210,12 @@ extern "C" int pnp_op_gemm_tokcols(int32_t bf, const void* d_A, int32_t lda, con
     return gemm_nt(bf, g, (hipStream_t)stream);
 }
 
+extern "C" int pnp_op_vit_attention(int32_t bf, const void* d_qk, int32_t ld_qk, int32_t D, const void* d_vt, int32_t ld_vt,
+                                    int32_t n_pad, void* d_ctx, int32_t B, int32_t heads, int32_t N, float scale, void* stream) {
+    if (!d_qk || !d_vt || !d_ctx || B <= 0 || heads <= 0 || N <= 0) return PNP_ERR_ARG;
+    return vit_attention(bf, d_qk, ld_qk, D, d_vt, ld_vt, n_pad, d_ctx, B, heads, N, scale, (hipStream_t)stream);
+}
+
 extern "C" int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                                 float* d_y, void* stream) {
     return layernorm(0, d_x, d_w, d_b, eps, rows, D, d_y, nullptr, nullptr, nullptr, (hipStream_t)stream);

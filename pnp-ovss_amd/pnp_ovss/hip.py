@@ -75,6 +75,7 @@ def load_library():
         "pnp_op_gemm": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
         "pnp_op_gemm_ex": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, vp]),
         "pnp_op_gemm_tokcols": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
+        "pnp_op_vit_attention": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, f32, vp]),
         "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
         "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
         "pnp_dbg_gemm_stamps": (i32, [vp, i32]),
@@ -92,7 +93,7 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_finalize_weights", "pnp_vit_forward", "pnp_text_forward_xattn", "pnp_xattn_grad",
             "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
-            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols"]
+            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention"]
 
 
 class _DevView:
