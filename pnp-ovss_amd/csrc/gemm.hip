@@ -583,10 +583,13 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                 }
             }
         }
-        float brow0 = 0.f;
+        float brow[TM] = {0.f, 0.f, 0.f, 0.f};        // TOKCOLS: bias of this lane's row in each 32-row tile
         if constexpr (EPI == WIDE_TOKCOLS_BF16) {
-            const int mbase = em0 + wm * 128;
-            if (g.bias && l32 == lane && mbase + lane < g.M) brow0 = g.bias[mbase + lane];
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+                const int m = em0 + wm * 128 + j * 32 + l32;
+                if (g.bias && m < g.M) brow[j] = g.bias[m];
+            }
         }
         const int next = tile + gridDim.x;
         if (next < ntiles) {                        // slab 0 of the next tile flies during this tile's epilogue
@@ -597,9 +600,14 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         if (g.ablate == 31 && tile == (int)blockIdx.x) stamp(1);
 
         if constexpr (EPI == WIDE_TOKCOLS_BF16) {
-            // one output row per store instruction: lane = token column, 128 contiguous bytes per row
-            const int tok = en0 + wn * 64 + lane;
-            const bool tv = tok < g.Nvalid;
+            // per-row bias and bf16 rounding in the accumulator layout, bf16 staging in two 64-row halves; on the way
+            // out a lane owns a PAIR of token columns (4-byte stores, 128 contiguous bytes per row, two rows per
+            // instruction) when col_div is even -- pairs then never straddle an image -- else single tokens
+            constexpr int HROW = 68;
+            bf16* const stgh = reinterpret_cast<bf16*>(smem + 65536) + wave * (64 * HROW);
+            const bool pairs = (g.col_div & 1) == 0;
+            const int tl0 = pairs ? 2 * l32 : lane;                      // token column inside the wave's 64
+            const int tok = en0 + wn * 64 + tl0;
             size_t ocol = tok;
             if (g.col_div > 0) {
                 const int b = tok / g.col_div;
@@ -611,24 +619,37 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                 ocol = (size_t)b * g.col_pad + tl;
             }
             bf16* const ocolp = reinterpret_cast<bf16*>(g.out_t) + ocol;
+            const bool tv = tok < g.Nvalid;         // Nvalid is even whenever col_div is (whole images)
 #pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                const int mbase = em0 + wm * 128 + qd * 32;
-                float brow = brow0;                 // lane l holds the bias of row mbase + l
-                if (qd > 0 && g.bias && l32 == lane && mbase + lane < g.M) brow = g.bias[mbase + lane];
+            for (int half = 0; half < 2; half++) {
+                const int mbase = em0 + wm * 128 + half * 64;
 #pragma unroll
-                for (int i = 0; i < TN; i++)
+                for (int jj = 0; jj < 2; jj++)
 #pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        const f32x16& a = acc[i][qd];
-                        const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
-                        *reinterpret_cast<f32x4*>(stg + l32 * SROW + i * 32 + gq * 8 + hi * 4) = v;
+                    for (int i = 0; i < TN; i++)
+#pragma unroll
+                        for (int gq = 0; gq < 4; gq++) {
+                            const f32x16& a = acc[i][half * 2 + jj];
+                            const float br = brow[half * 2 + jj];
+                            const bf16x4 pk = {(bf16)(a[gq * 4] + br), (bf16)(a[gq * 4 + 1] + br), (bf16)(a[gq * 4 + 2] + br),
+                                               (bf16)(a[gq * 4 + 3] + br)};
+                            *reinterpret_cast<bf16x4*>(stgh + (jj * 32 + l32) * HROW + i * 32 + gq * 8 + hi * 4) = pk;
+                        }
+                if (pairs) {
+                    uint32_t sv[32];
+#pragma unroll
+                    for (int it = 0; it < 32; it++) sv[it] = *reinterpret_cast<const uint32_t*>(stgh + (it * 2 + hi) * HROW + tl0);
+#pragma unroll
+                    for (int it = 0; it < 32; it++) {
+                        const int m = mbase + it * 2 + hi;
+                        if (tv && m < g.M) *reinterpret_cast<uint32_t*>(ocolp + (size_t)m * g.ldo_t) = sv[it];
                     }
-#pragma unroll
-                for (int row = 0; row < 32; row++) {
-                    const float v = stg[row * SROW + lane] +
-                                    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, brow), row));
-                    if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo_t] = (bf16)v;
+                } else {
+#pragma unroll 8
+                    for (int row = 0; row < 64; row++) {
+                        const bf16 v = stgh[row * HROW + lane];
+                        if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo_t] = v;
+                    }
                 }
             }
         } else if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16) {

@@ -103,7 +103,7 @@ def test_gemm_wide_tile_epilogues(kind, shape):
     ref = A.double() @ B.double().t()
     p = lambda t: t.data_ptr() if t is not None else None
     if kind == "tokcols":
-        div, pad = 442, 448
+        div, pad = (442, 448) if K > 64 else (577, 640)      # even: token pairs per lane; odd: single tokens
         nimg = (N + div - 1) // div
         bias = torch.randn(M, generator=g).cuda()
         out = torch.zeros(M, nimg * pad, device="cuda", dtype=torch.bfloat16)
