@@ -136,6 +136,24 @@ int pnp_remap_hist(pnp_engine* e, int32_t from_crf, uint8_t* d_labels, unsigned 
 int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T, float threshold, int32_t scale01, int32_t mode,
                     uint8_t* d_labels, unsigned long long* d_hist, int32_t n_class, void* stream);
 
+/* ---- input side ("next" row: the tensors the reference's datasets hand to the model) -------
+ * Dataset.py:434-443: transforms.Resize((S, S), BICUBIC) on the PIL image -> ToTensor -> Normalize(mean, std).
+ * Pillow's 8-bit two-pass resampler (src/libImaging/Resample.c) in integer arithmetic, bit-exact: per axis and
+ * output index o the host supplies (first tap, tap count) and 22-bit fixed-point taps (pnp_ovss.hip
+ * .resample_table, the double-precision recipe of precompute_coeffs / normalize_coeffs_8bpc);
+ * out = clip8((2^21 + sum taps * pixel) >> 22), horizontal pass first with a uint8 intermediate; then
+ * (v / 255 - mean[c]) / std[c] in fp32.  Stateless; all pointers are device pointers except mean3 / std3. */
+typedef struct pnp_pre_image {
+    int64_t src_off;            /* byte offset of the image in d_rgb (H*W*3, row-major HWC uint8) */
+    int64_t tmp_off;            /* byte offset of its H x S x 3 intermediate in d_tmp */
+    int32_t H, W;
+    int32_t kx_off, kx_size;    /* horizontal table at d_coef[kx_off]: S x (2 + kx_size) int32 = first, count, taps... */
+    int32_t ky_off, ky_size;    /* vertical table, same layout */
+} pnp_pre_image;
+int pnp_preprocess_images(const uint8_t* d_rgb, const pnp_pre_image* d_desc, int32_t B, int32_t S, int32_t max_H,
+                          const int32_t* d_coef, uint8_t* d_tmp, const float* mean3, const float* std3, float* d_out,
+                          void* stream);
+
 /* ---- introspection (tests / profiling) --------------------------------------------------- */
 /* Named internal device buffers: "image_embeds" (fp32 B*N*D), "maps" (fp32 post-process maps),
  * "crf_q", "P", "dP", "crf_M" (int32 [2][B+1] lattice id bases), ... */

@@ -1234,6 +1234,14 @@ extern "C" int pnp_dbg_gemm_stamps(uint64_t* host_out, int32_t max_blocks) {
     return gemm_read_stamps((unsigned long long*)host_out, max_blocks);
 }
 
+extern "C" int pnp_preprocess_images(const uint8_t* d_rgb, const pnp_pre_image* d_desc, int32_t B, int32_t S, int32_t max_H,
+                                     const int32_t* d_coef, uint8_t* d_tmp, const float* mean3, const float* std3,
+                                     float* d_out, void* stream) {
+    if (!d_rgb || !d_desc || !d_coef || !d_tmp || !mean3 || !std3 || !d_out) return PNP_ERR_ARG;
+    static_assert(sizeof(pnp_pre_image) == 40, "pnp_pre_image layout is part of the ABI");
+    return preprocess_images(d_rgb, d_desc, B, S, max_H, d_coef, d_tmp, mean3, std3, d_out, (hipStream_t)stream);
+}
+
 extern "C" int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream) {
     return cast_f32(to_bf16, d_in, d_out, (size_t)n, (hipStream_t)stream);
 }

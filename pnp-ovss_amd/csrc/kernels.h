@@ -75,6 +75,8 @@ int minmax_normalize(float* maps, const PostDesc* desc, float* stats, int B, int
 int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipStream_t s);
 int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
               int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s);
+int preprocess_images(const uint8_t* rgb, const void* desc, int B, int S, int max_H, const int32_t* coef, uint8_t* tmp,
+                      const float* mean3, const float* std3, float* out, hipStream_t s);
 int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, hipStream_t s);
 int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int lut_stride, uint8_t* labels,
                  const size_t* label_off, int pixel_major, int B, int maxHW, hipStream_t s);

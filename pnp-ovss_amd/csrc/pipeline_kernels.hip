@@ -412,6 +412,72 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Input side: Pillow's 8-bit bicubic resampler + ToTensor + Normalize (Dataset.py:434-443), integer exact.
+// Tables: per output index (first tap, tap count, taps[ksize]) in 22-bit fixed point, built on the host.
+struct PreImage {           // mirrors pnp_pre_image (include/pnp_hip.h)
+    int64_t src_off, tmp_off;
+    int32_t H, W, kx_off, kx_size, ky_off, ky_size;
+};
+__device__ __forceinline__ int clip8_fixed(int acc) {
+    const int v = (acc + (1 << 21)) >> 22;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+// horizontal: tmp[y][xo][c] for all rows of the image; one thread per (row, output column)
+__global__ __launch_bounds__(256) void pre_resize_h_kernel(const uint8_t* __restrict__ rgb, const PreImage* __restrict__ desc,
+                                                           int S, const int32_t* __restrict__ coef, uint8_t* __restrict__ tmp) {
+    const PreImage d = desc[blockIdx.z];
+    const int xo = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xo >= S || y >= d.H) return;
+    const int32_t* t = coef + d.kx_off + (size_t)xo * (2 + d.kx_size);
+    const int x0 = t[0], n = t[1];
+    const uint8_t* row = rgb + d.src_off + ((size_t)y * d.W + x0) * 3;
+    int a0 = 0, a1 = 0, a2 = 0;
+    for (int i = 0; i < n; i++) {
+        const int w = t[2 + i];
+        a0 += w * row[3 * i];
+        a1 += w * row[3 * i + 1];
+        a2 += w * row[3 * i + 2];
+    }
+    uint8_t* o = tmp + d.tmp_off + ((size_t)y * S + xo) * 3;
+    o[0] = (uint8_t)clip8_fixed(a0);
+    o[1] = (uint8_t)clip8_fixed(a1);
+    o[2] = (uint8_t)clip8_fixed(a2);
+}
+// vertical + ToTensor + Normalize: out[b][c][yo][xo]
+__global__ __launch_bounds__(256) void pre_resize_v_kernel(const uint8_t* __restrict__ tmp, const PreImage* __restrict__ desc,
+                                                           int S, const int32_t* __restrict__ coef, float m0, float m1, float m2,
+                                                           float s0, float s1, float s2, float* __restrict__ out) {
+    const PreImage d = desc[blockIdx.z];
+    const int xo = blockIdx.x * 64 + (threadIdx.x & 63), yo = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (xo >= S || yo >= S) return;
+    const int32_t* t = coef + d.ky_off + (size_t)yo * (2 + d.ky_size);
+    const int y0 = t[0], n = t[1];
+    const uint8_t* col = tmp + d.tmp_off + ((size_t)y0 * S + xo) * 3;
+    int a0 = 0, a1 = 0, a2 = 0;
+    for (int i = 0; i < n; i++) {
+        const int w = t[2 + i];
+        const uint8_t* p = col + (size_t)i * S * 3;
+        a0 += w * p[0];
+        a1 += w * p[1];
+        a2 += w * p[2];
+    }
+    float* o = out + (size_t)blockIdx.z * 3 * S * S + (size_t)yo * S + xo;
+    o[0] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8_fixed(a0), 255.0f), m0), s0);
+    o[(size_t)S * S] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8_fixed(a1), 255.0f), m1), s1);
+    o[(size_t)2 * S * S] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8_fixed(a2), 255.0f), m2), s2);
+}
+
+int preprocess_images(const uint8_t* rgb, const void* desc, int B, int S, int max_H, const int32_t* coef, uint8_t* tmp,
+                      const float* mean3, const float* std3, float* out, hipStream_t s) {
+    if (B <= 0 || S <= 0 || max_H <= 0) return PNP_ERR_ARG;
+    const PreImage* d = reinterpret_cast<const PreImage*>(desc);
+    hipLaunchKernelGGL(pre_resize_h_kernel, dim3((S + 63) / 64, (max_H + 3) / 4, B), dim3(256), 0, s, rgb, d, S, coef, tmp);
+    hipLaunchKernelGGL(pre_resize_v_kernel, dim3((S + 63) / 64, (S + 3) / 4, B), dim3(256), 0, s, tmp, d, S, coef, mean3[0],
+                       mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+// ------------------------------------------------------------------------------------------
 // softmax over channels + unary = -log(clip(p, 1e-5, 1)), written pixel-major [n][K]
 // (densecrf's value layout).  include/pnp_math.h defines exp/log bit-exactly for host and device.
 __global__ void unary_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc, float* __restrict__ unary) {

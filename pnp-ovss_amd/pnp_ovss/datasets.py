@@ -3,7 +3,8 @@ deliver to the driver (`img0`, `img_id`, original RGB for the CRF, ground-truth 
 across ranks like `DataLoader(..., sampler=DistributedSampler(dataset))` (Load_datasets.py:15-26).
 
   synthetic  seeded images + one-word-piece-per-class captions (no files needed; bench / CI)
-  voc        Dataset.py:349-445 (bicubic resize to img_size, CLIP mean/std), PnP.py:901-955 (GT / RGB)
+  voc        Dataset.py:349-445 (bicubic resize to img_size, CLIP mean/std: on device, bit-identical to the
+             Pillow / torchvision host path -- pnp_preprocess_images), PnP.py:901-955 (GT / RGB)
   psc        Dataset.py:889-991 (same transform), Pascal-Context 59 classes (Load_datasets.py:30-44)
 ADE20K / COCO loaders are the next row; they need files that are not in this image.
 """
@@ -35,10 +36,17 @@ class _Base:
         return host.shard_indices(n, self.rank, self.world, seed=0, shuffle=True)
 
     def batches(self, batch_size):
+        """Items whose first element is None get their model tensor from the device-side resize + normalise
+        (hip.preprocess_images: Pillow-exact bicubic, Dataset.py:434-443) over the decoded RGB the CRF uses anyway."""
         idx = self._indices(len(self))
         for o in range(0, len(idx), batch_size):
             items = [self[i] for i in idx[o:o + batch_size]]
-            yield {"imgs": torch.stack([it[0] for it in items]), "img_ids": [it[1] for it in items],
+            if items[0][0] is None:
+                from . import hip
+                imgs = hip.preprocess_images([it[2] for it in items], self.args.img_size, synth.CLIP_MEAN, synth.CLIP_STD)
+            else:
+                imgs = torch.stack([it[0] for it in items])
+            yield {"imgs": imgs, "img_ids": [it[1] for it in items],
                    "org_images": [it[2] for it in items], "label_trues": [it[3] for it in items]}
 
 
@@ -94,15 +102,12 @@ class VocLikeDataset(_Base):
     def __getitem__(self, i):
         from PIL import Image
         img_id = self.ids[i]
-        img = Image.open(os.path.join(self.img_dir, img_id + ".jpg")).convert("RGB")
+        img = Image.open(os.path.join(self.img_dir, img_id + ".jpg")).convert("RGB")     # JPEG decode stays on the host
         org = np.asarray(img)
-        S = self.args.img_size
-        x = np.asarray(img.resize((S, S), Image.BICUBIC), dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
-        x = (x - self.mean) / self.std
         gt = np.float32(Image.open(os.path.join(self.gt_dir, img_id + ".png")))
         if self.kind == "voc":
             gt[gt == 255] = 0                                    # PnP.py:908
-        return torch.from_numpy(np.ascontiguousarray(x)), img_id, org, gt
+        return None, img_id, org, gt                             # tensor: device resize + normalise per batch
 
     def predicted_classes(self, img_id):
         return self.gpt.lookup(img_id, self.nms)

@@ -76,6 +76,7 @@ def load_library():
         "pnp_op_gemm_ex": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, vp]),
         "pnp_op_gemm_tokcols": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
         "pnp_op_vit_attention": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, f32, vp]),
+        "pnp_preprocess_images": (i32, [vp, vp, i32, i32, i32, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
         "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
         "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
         "pnp_dbg_gemm_stamps": (i32, [vp, i32]),
@@ -93,7 +94,7 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_finalize_weights", "pnp_vit_forward", "pnp_text_forward_xattn", "pnp_xattn_grad",
             "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
-            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention"]
+            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images"]
 
 
 class _DevView:
@@ -117,6 +118,83 @@ def _ptr(t):
 
 def _i32p(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class PnpPreImage(C.Structure):
+    _fields_ = [("src_off", C.c_int64), ("tmp_off", C.c_int64), ("H", C.c_int32), ("W", C.c_int32),
+                ("kx_off", C.c_int32), ("kx_size", C.c_int32), ("ky_off", C.c_int32), ("ky_size", C.c_int32)]
+
+
+_RESAMPLE_CACHE = {}
+
+
+def resample_table(in_size, out_size):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter over the whole axis
+    (src/libImaging/Resample.c), as one int32 array [out_size, 2 + ksize] = (first tap, tap count, taps).
+    Double precision, then 22-bit fixed point -- the kernel's only inputs besides the pixels."""
+    key = (int(in_size), int(out_size))
+    if key in _RESAMPLE_CACHE:
+        return _RESAMPLE_CACHE[key]
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(np.ceil(support)) * 2 + 1
+    tab = np.zeros((out_size, 2 + ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    a = -0.5
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        x = np.abs((np.arange(xmax) + xmin - center + 0.5) * ss)
+        w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+        ww = 0.0
+        for v in w:                                   # sequential sum, as the C loop
+            ww += float(v)
+        if ww != 0.0:
+            w = w / ww
+        tab[xx, 0], tab[xx, 1] = xmin, xmax
+        tab[xx, 2:2 + xmax] = [int(-0.5 + float(v) * (1 << 22)) if v < 0 else int(0.5 + float(v) * (1 << 22)) for v in w]
+    _RESAMPLE_CACHE[key] = (tab, ksize)
+    return tab, ksize
+
+
+def preprocess_images(images, S, mean, std, device=None):
+    """Dataset.py:434-443 on device: list of RGB uint8 arrays [H, W, 3] (any sizes) -> float32 tensor [B, 3, S, S]
+    = Normalize(ToTensor(PIL bicubic resize)), bit-identical to the Pillow / torchvision host path."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("pnp_ovss.hip.preprocess_images needs a HIP device (no CPU fallback)")
+    lib = load_library()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    B = len(images)
+    desc = (PnpPreImage * B)()
+    coef_parts, coef_off, cache = [], 0, {}
+    src_off = tmp_off = 0
+    for i, im in enumerate(images):
+        H, W = int(im.shape[0]), int(im.shape[1])
+        for axis, n in (("x", W), ("y", H)):
+            if (n, S) not in cache:
+                tab, ks = resample_table(n, S)
+                cache[(n, S)] = (coef_off, ks)
+                coef_parts.append(tab.reshape(-1))
+                coef_off += tab.size
+        kx, ky = cache[(W, S)], cache[(H, S)]
+        desc[i] = PnpPreImage(src_off, tmp_off, H, W, kx[0], kx[1], ky[0], ky[1])
+        src_off += H * W * 3
+        tmp_off += H * S * 3
+    rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(im, dtype=np.uint8).reshape(-1) for im in images])).to(dev)
+    coef = torch.from_numpy(np.concatenate(coef_parts)).to(dev)
+    d_desc = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
+    tmp = torch.empty(tmp_off, dtype=torch.uint8, device=dev)
+    out = torch.empty(B, 3, S, S, dtype=torch.float32, device=dev)
+    m3 = (C.c_float * 3)(*[float(np.float32(v)) for v in mean])
+    s3 = (C.c_float * 3)(*[float(np.float32(v)) for v in std])
+    r = lib.pnp_preprocess_images(rgb.data_ptr(), d_desc.data_ptr(), B, S, max(int(im.shape[0]) for im in images), coef.data_ptr(),
+                                  tmp.data_ptr(), m3, s3, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if r != 0:
+        raise RuntimeError(f"pnp_preprocess_images failed ({r})")
+    return out
 
 
 def gaussian_taps(H, W, scale=0.05, truncate=4.0):

@@ -325,9 +325,35 @@ def gen_hist_cases():
     print("hist_cases: mIoU", acc["Mean IoU"])
 
 
+def gen_preprocess_cases():
+    """Dataset.py:434-443 on synthetic RGB images: Pillow bicubic resize (the library call behind
+    transforms.Resize on a PIL image) -> /255 -> (x - mean) / std in float32, as torchvision's ToTensor /
+    Normalize compute them.  Inputs are small; outputs are stored as the resized uint8 image (the float tensor is
+    a deterministic float32 function of it, re-derived in the tests)."""
+    from PIL import Image
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = [(75, 100, 64), (100, 67, 64), (24, 32, 48), (64, 64, 64), (57, 100, 96), (160, 107, 48), (17, 19, 16)]
+    for i, (H, W, S) in enumerate(cases):
+        coarse = rng.integers(0, 256, size=((H + 7) // 8, (W + 7) // 8, 3))
+        img = np.clip(np.repeat(np.repeat(coarse, 8, 0), 8, 1)[:H, :W] + rng.integers(-20, 21, size=(H, W, 3)), 0, 255).astype(np.uint8)
+        res = np.asarray(Image.fromarray(img).resize((S, S), Image.BICUBIC))
+        t = torch.from_numpy(res.copy()).permute(2, 0, 1).float().div(255)
+        mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)
+        std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)
+        t = (t - mean) / std
+        out[f"img{i}"], out[f"res{i}"], out[f"S{i}"] = img, res, np.int32(S)
+        out[f"tensor_sha{i}"] = np.frombuffer(__import__("hashlib").sha256(t.numpy().tobytes()).digest(), dtype=np.uint8)
+    out["n"] = np.int32(len(cases))
+    import PIL
+    out["pillow_version"] = np.array(PIL.__version__)
+    np.savez_compressed(os.path.join(HERE, "preprocess_cases.npz"), **out)
+    print("preprocess_cases:", len(cases), "cases, Pillow", PIL.__version__)
+
+
 GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, droploop_small=gen_droploop_small,
             merge_tokens=gen_merge_tokens, pipeline_voc=gen_pipeline_voc, pipeline_psc=gen_pipeline_psc, gpt_parse=gen_gpt_parse,
-            blur_cases=gen_blur_cases, hist_cases=gen_hist_cases)
+            blur_cases=gen_blur_cases, hist_cases=gen_hist_cases, preprocess_cases=gen_preprocess_cases)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -61,3 +61,42 @@ def test_cli_synthetic_end_to_end(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "pnp-ovss_amd", "Calculate_mIoU.py"), "--save_path", str(save)],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "Mean IoU" in r.stdout
+
+
+def test_voc_dataset_device_preprocess_equals_host_pillow_path(tmp_path):
+    """`--data_type voc` input side on a tiny fake VOCdevkit: the batch tensor produced by the device resize +
+    normalise equals the reference's host recipe (PIL bicubic resize -> /255 -> (x - mean) / std, Dataset.py:434-443)
+    byte for byte; ids / RGB / ground truth come through as the driver expects (PnP.py:901-955)."""
+    import types
+    from PIL import Image
+    from pnp_ovss import datasets, synth
+    root = tmp_path / "VOCdevkit" / "VOC2012"
+    for d in ("JPEGImages", "SegmentationClass", "ImageSets/Segmentation"):
+        (root / d).mkdir(parents=True)
+    (tmp_path / "GPT4o_classification").mkdir()
+    rng = np.random.default_rng(3)
+    ids, table = [], {}
+    for i, (h, w) in enumerate(((75, 100), (100, 67), (64, 64))):
+        name = f"2008_{i:06d}"
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(root / "JPEGImages" / f"{name}.jpg", quality=95)
+        gt = rng.integers(0, 21, size=(h, w)).astype(np.uint8)
+        gt[0, 0] = 255
+        Image.fromarray(gt).save(root / "SegmentationClass" / f"{name}.png")
+        ids.append(name)
+        table[name] = "[[1: aeroplane, 95%], [12: dog, 80%]]"
+    (root / "ImageSets/Segmentation/val.txt").write_text("\n".join(ids) + "\n")
+    (tmp_path / "GPT4o_classification" / "voc_classification_noboundary.json").write_text(json.dumps(table))
+    args = types.SimpleNamespace(home_dir=str(tmp_path), img_size=64, data_type="voc")
+    ds = datasets.make_dataset(args, 0, 1)
+    batches = list(ds.batches(2))
+    assert sum(len(b["img_ids"]) for b in batches) == 3
+    mean = np.array(synth.CLIP_MEAN, dtype=np.float32).reshape(3, 1, 1)
+    std = np.array(synth.CLIP_STD, dtype=np.float32).reshape(3, 1, 1)
+    for b in batches:
+        got = b["imgs"].cpu().numpy()
+        for j, name in enumerate(b["img_ids"]):
+            img = Image.open(root / "JPEGImages" / f"{name}.jpg").convert("RGB")
+            x = np.asarray(img.resize((64, 64), Image.BICUBIC), dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
+            assert np.array_equal(got[j], (x - mean) / std), name
+            assert np.array_equal(b["org_images"][j], np.asarray(img))
+            assert b["label_trues"][j].dtype == np.float32 and b["label_trues"][j][0, 0] == 0      # 255 -> 0 (PnP.py:908)

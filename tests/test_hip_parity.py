@@ -610,3 +610,21 @@ def test_gradcam_768_geometry_vs_oracle():
     pre = OP.threshold_upsample(merged, 768, 768, 0.15, False, True)
     lab = OP.postprocess("blur", pre, None, (768, 768))
     np.testing.assert_array_equal(labels[0].cpu().numpy().astype(np.float32), lab)
+
+
+def test_preprocess_images_bit_exact():
+    """pnp_preprocess_images (Pillow bicubic resize + ToTensor + Normalize on device) == oracle, bit for bit, on
+    the Pillow goldens and on a ragged batch of larger images (down- and up-scaling, identity axis)."""
+    from pnp_ovss import hip
+    from oracle import preprocess_np as PP
+    g = _golden("preprocess_cases.npz")
+    for i in range(int(g["n"])):
+        img, S = g[f"img{i}"], int(g[f"S{i}"])
+        out = hip.preprocess_images([img], S, PP.CLIP_MEAN, PP.CLIP_STD)
+        torch.cuda.synchronize()
+        assert np.array_equal(out[0].cpu().numpy(), PP.vit_preprocess(img, S)), i
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in ((375, 500, 3), (500, 333, 3), (336, 400, 3), (120, 90, 3))]
+    out = hip.preprocess_images(imgs, 336, PP.CLIP_MEAN, PP.CLIP_STD).cpu().numpy()
+    for i, im in enumerate(imgs):
+        assert np.array_equal(out[i], PP.vit_preprocess(im, 336)), i

@@ -196,3 +196,29 @@ def test_blur_matches_scipy_directly():
         x = rng.random((h, w), dtype=np.float32)
         sig = 0.05 * max(h, w)
         np.testing.assert_array_equal(OP.gaussian_blur(x, sig), ndi.gaussian_filter(x, sig))
+
+
+def test_preprocess_matches_pillow_golden(golden_dir):
+    """Input side: the oracle's Pillow-resampler restatement against vectors produced by
+    Pillow itself (tests/golden/make_golden.py:gen_preprocess_cases) -- resized uint8 images bit-exact, and the
+    normalised float32 tensor identical byte for byte to torchvision-style ToTensor / Normalize (SHA-256)."""
+    import hashlib
+    from oracle import preprocess_np as PP
+    g = np.load(os.path.join(golden_dir, "preprocess_cases.npz"), allow_pickle=False)
+    for i in range(int(g["n"])):
+        img, S = g[f"img{i}"], int(g[f"S{i}"])
+        res = PP.resize_bicubic_u8(img, S)
+        assert np.array_equal(res, g[f"res{i}"]), i
+        t = PP.vit_preprocess(img, S)
+        assert t.dtype == np.float32 and t.shape == (3, S, S)
+        assert hashlib.sha256(np.ascontiguousarray(t).tobytes()).digest() == g[f"tensor_sha{i}"].tobytes(), i
+
+
+def test_preprocess_tables_host_equals_oracle():
+    """The host-side table builder the HIP kernel is fed with (pnp_ovss.hip.resample_table) == the oracle's."""
+    from pnp_ovss import hip
+    from oracle import preprocess_np as PP
+    for n, S in ((500, 336), (375, 336), (64, 96), (336, 336), (1024, 336), (17, 16), (281, 768)):
+        tab, ks = hip.resample_table(n, S)
+        b, kk = PP.resample_coeffs(n, S)
+        assert ks == kk.shape[1] and np.array_equal(tab[:, :2], b) and np.array_equal(tab[:, 2:], kk), (n, S)

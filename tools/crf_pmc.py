@@ -20,7 +20,7 @@ fine = g.integers(-4, 5, size=(B, IMG, IMG, 3))
 rgb = np.clip(np.repeat(np.repeat(coarse, 8, 1), 8, 2) + fine, 0, 255).astype(np.uint8)
 d_rgb = torch.from_numpy(rgb.reshape(-1)).cuda()
 e = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, bf16=True)
-e.post_reserve(B, B * IMG * IMG, IMG * IMG, K, 0)
+e.post_reserve(B, B * IMG * IMG, IMG * IMG, K, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 e.post_prepare([(IMG, IMG)] * B, plans, luts, [True] * B, rgb=d_rgb, gt=None, want_crf=True)
 e.merge_tokens(d_maps); e.threshold_upsample(0.15, False); e.blur_minmax()
 torch.cuda.synchronize()
