@@ -941,6 +941,9 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
         g.N = (g.N + 63) / 64 * 64;
         static const int small_variant = getenv("PNP_GEMM_SMALL") ? atoi(getenv("PNP_GEMM_SMALL")) : 0;
         if (small_variant == 1) return dtype_bf16 ? launch_cfg<bf16, 64, 64>(g, s) : launch_cfg<float, 64, 64>(g, s);
+        static const int small_ns = getenv("PNP_GEMM_SMALL_NS") ? atoi(getenv("PNP_GEMM_SMALL_NS")) : 3;
+        if (dtype_bf16 && small_ns == 4) return launch_big<bf16, 64, 64, 32, 32, 4>(g, s);
+        if (dtype_bf16 && small_ns == 6) return launch_big<bf16, 64, 64, 32, 32, 6>(g, s);
         return dtype_bf16 ? launch_big<bf16, 64, 64, 32, 32, 3>(g, s) : launch_big<float, 64, 64, 32, 32, 3>(g, s);
     }
     GemmProfile& pf = gemm_profile();
