@@ -6,8 +6,11 @@ across ranks like `DataLoader(..., sampler=DistributedSampler(dataset))` (Load_d
   voc        Dataset.py:349-445 (bicubic resize to img_size, CLIP mean/std: on device, bit-identical to the
              Pillow / torchvision host path -- pnp_preprocess_images), PnP.py:901-955 (GT / RGB)
   psc        Dataset.py:889-991 (same transform), Pascal-Context 59 classes (Load_datasets.py:30-44)
-ADE20K / COCO loaders are the next row; they need files that are not in this image.
+  ade20k     Dataset.py:1181-1296 (PIL *bilinear* resize, ToTensor only), Load_datasets.py:60-104 (150 classes, names
+             with blanks removed, validation.odgt list), PnP.py:917-923 / 945-952 (GT / RGB by "ADE_val_%08d")
+COCO (PnP_OVSS_0514_updated_segmentation_coco.py, pycocotools) is the remaining loader.
 """
+import json
 import os
 
 import numpy as np
@@ -19,6 +22,18 @@ PSC_NAMES = ("aeroplane bag bed bedclothes bench bicycle bird boat book bottle b
              "chair cloth computer cow cup curtain dog door fence floor flower food grass ground horse keyboard light "
              "motorbike mountain mouse person plate platform pottedplant road rock sheep shelves sidewalk sign sky snow "
              "sofa table track train tree truck tvmonitor wall water window wood").split()
+
+
+ADE_NAMES = ("wall,building,sky,floor,tree,ceiling,road,bed,windowpane,grass,cabinet,sidewalk,person,ground,door,table,mountain,"
+             "plant,curtain,chair,car,water,painting,sofa,shelf,house,sea,mirror,rug,field,armchair,seat,fence,desk,rock,wardrobe,"
+             "lamp,bathtub,railing,cushion,base,box,pillar,signboard,chest of drawers,counter,sand,sink,skyscraper,fireplace,"
+             "refrigerator,grandstand,path,stairs,runway,case,billiard table,pillow,screen,stairway,river,bridge,bookcase,blind,"
+             "coffee table,toilet,flower,book,hill,bench,countertop,stove,palm,kitchen island,computer,swivel chair,boat,bar,"
+             "arcade machine,hovel,bus,towel,light,truck,tower,chandelier,sunshade,streetlight,booth,television receiver,airplane,"
+             "dirt track,apparel,pole,land,bannister,escalator,ottoman,bottle,buffet,poster,stage,van,ship,fountain,conveyer belt,"
+             "canopy,washer,toy,swimming pool,stool,barrel,basket,waterfall,tent,bag,motorbike,cradle,oven,ball,food,stair,tank,"
+             "marque,microwave,pot,animal,bicycle,lake,dishwasher,screen,blanket,sculpture,hood,sconce,vase,trafficlight,tray,"
+             "trash can,fan,pier,crt screen,plate,monitor,bulletinboard,shower,radiator,glass,clock,flag").split(",")
 
 
 class _Base:
@@ -35,15 +50,18 @@ class _Base:
     def _indices(self, n):
         return host.shard_indices(n, self.rank, self.world, seed=0, shuffle=True)
 
+    resample = ("bicubic", synth.CLIP_MEAN, synth.CLIP_STD)      # Dataset.py:434-443
+
     def batches(self, batch_size):
         """Items whose first element is None get their model tensor from the device-side resize + normalise
-        (hip.preprocess_images: Pillow-exact bicubic, Dataset.py:434-443) over the decoded RGB the CRF uses anyway."""
+        (hip.preprocess_images: Pillow-exact, Dataset.py:434-443 / :1263) over the decoded RGB the CRF uses anyway."""
         idx = self._indices(len(self))
         for o in range(0, len(idx), batch_size):
             items = [self[i] for i in idx[o:o + batch_size]]
             if items[0][0] is None:
                 from . import hip
-                imgs = hip.preprocess_images([it[2] for it in items], self.args.img_size, synth.CLIP_MEAN, synth.CLIP_STD)
+                filt, mean, std = self.resample
+                imgs = hip.preprocess_images([it[2] for it in items], self.args.img_size, mean, std, filt=filt)
             else:
                 imgs = torch.stack([it[0] for it in items])
             yield {"imgs": imgs, "img_ids": [it[1] for it in items],
@@ -113,9 +131,44 @@ class VocLikeDataset(_Base):
         return self.gpt.lookup(img_id, self.nms)
 
 
+class Ade20kDataset(_Base):
+    """`--data_type ade20k`: 150 classes, 768-pixel inputs, up to 150 channels per image."""
+    max_text_len = 192
+    max_channels = 152
+    resample = ("bilinear", (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))    # imresize(..., 'bilinear') + ToTensor only (Dataset.py:1263-1275)
+
+    def __init__(self, args, rank, world_size):
+        from PIL import Image                                    # noqa: F401
+        super().__init__(args, rank, world_size, {i + 1: n for i, n in enumerate(ADE_NAMES)})
+        self.nms = ["".join(n.split(" ")) for n in self.cats.values()]           # Load_datasets.py:87
+        home = args.home_dir
+        with open(f"{home}/semantic-segmentation-pytorch-master/data/validation.odgt") as f:
+            self.records = [json.loads(l) for l in f if l.strip()]
+        self.gpt = host.GptClassTable(f"{home}/GPT4o_classification/ade20k_classification_noboundary.json", "ade20k")
+        self.max_pixels = int(getattr(args, "max_pixels", 0)) or 2100 * 2100
+
+    def __len__(self):
+        return len(self.records)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        rec = self.records[i]
+        img_id = rec["fpath_img"].split(".")[0].split("/")[-1].split("_")[-1].lstrip("0")     # Dataset.py:1270
+        stem = "ADE_val_" + img_id.rjust(8, "0")
+        home = self.args.home_dir
+        org = np.asarray(Image.open(f"{home}/ADEChallengeData2016/images/validation/{stem}.jpg").convert("RGB"))
+        gt = np.float32(Image.open(f"{home}/ADEChallengeData2016/annotations/validation/{stem}.png"))      # PnP.py:917-923
+        return None, img_id, org, gt
+
+    def predicted_classes(self, img_id):
+        return self.gpt.lookup(img_id, self.nms)
+
+
 def make_dataset(args, rank, world_size):
     if args.data_type == "synthetic":
         return SyntheticDataset(args, rank, world_size)
     if args.data_type in ("voc", "psc"):
         return VocLikeDataset(args, rank, world_size, args.data_type)
-    raise SystemExit(f"--data_type {args.data_type!r}: supported here: synthetic, voc, psc (ade20k / coco loaders are next)")
+    if args.data_type == "ade20k":
+        return Ade20kDataset(args, rank, world_size)
+    raise SystemExit(f"--data_type {args.data_type!r}: supported here: synthetic, voc, psc, ade20k (the COCO driver is next)")

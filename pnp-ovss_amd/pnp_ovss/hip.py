@@ -128,17 +128,19 @@ class PnpPreImage(C.Structure):
 _RESAMPLE_CACHE = {}
 
 
-def resample_table(in_size, out_size):
-    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic filter over the whole axis
+def resample_table(in_size, out_size, filt="bicubic"):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bicubic / bilinear filter over the whole axis
     (src/libImaging/Resample.c), as one int32 array [out_size, 2 + ksize] = (first tap, tap count, taps).
     Double precision, then 22-bit fixed point -- the kernel's only inputs besides the pixels."""
-    key = (int(in_size), int(out_size))
+    key = (int(in_size), int(out_size), filt)
+    if filt not in ("bicubic", "bilinear"):
+        raise ValueError(f"unknown resampling filter {filt!r}")
     if key in _RESAMPLE_CACHE:
         return _RESAMPLE_CACHE[key]
     scale = filterscale = float(in_size) / out_size
     if filterscale < 1.0:
         filterscale = 1.0
-    support = 2.0 * filterscale
+    support = (2.0 if filt == "bicubic" else 1.0) * filterscale
     ksize = int(np.ceil(support)) * 2 + 1
     tab = np.zeros((out_size, 2 + ksize), dtype=np.int32)
     ss = 1.0 / filterscale
@@ -148,7 +150,10 @@ def resample_table(in_size, out_size):
         xmin = max(int(center - support + 0.5), 0)
         xmax = min(int(center + support + 0.5), in_size) - xmin
         x = np.abs((np.arange(xmax) + xmin - center + 0.5) * ss)
-        w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+        if filt == "bicubic":
+            w = np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+        else:
+            w = np.where(x < 1.0, 1.0 - x, 0.0)
         ww = 0.0
         for v in w:                                   # sequential sum, as the C loop
             ww += float(v)
@@ -160,9 +165,10 @@ def resample_table(in_size, out_size):
     return tab, ksize
 
 
-def preprocess_images(images, S, mean, std, device=None):
+def preprocess_images(images, S, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), device=None, filt="bicubic"):
     """Dataset.py:434-443 on device: list of RGB uint8 arrays [H, W, 3] (any sizes) -> float32 tensor [B, 3, S, S]
-    = Normalize(ToTensor(PIL bicubic resize)), bit-identical to the Pillow / torchvision host path."""
+    = Normalize(ToTensor(PIL resize)), bit-identical to the Pillow / torchvision host path.  ADE20K (Dataset.py:1263,
+    1272-1275) is filt="bilinear" with the default mean 0 / std 1 ((v - 0) / 1 is exact)."""
     if not torch.cuda.is_available():
         raise RuntimeError("pnp_ovss.hip.preprocess_images needs a HIP device (no CPU fallback)")
     lib = load_library()
@@ -175,7 +181,7 @@ def preprocess_images(images, S, mean, std, device=None):
         H, W = int(im.shape[0]), int(im.shape[1])
         for axis, n in (("x", W), ("y", H)):
             if (n, S) not in cache:
-                tab, ks = resample_table(n, S)
+                tab, ks = resample_table(n, S, filt)
                 cache[(n, S)] = (coef_off, ks)
                 coef_parts.append(tab.reshape(-1))
                 coef_off += tab.size

@@ -338,6 +338,7 @@ def gen_preprocess_cases():
         coarse = rng.integers(0, 256, size=((H + 7) // 8, (W + 7) // 8, 3))
         img = np.clip(np.repeat(np.repeat(coarse, 8, 0), 8, 1)[:H, :W] + rng.integers(-20, 21, size=(H, W, 3)), 0, 255).astype(np.uint8)
         res = np.asarray(Image.fromarray(img).resize((S, S), Image.BICUBIC))
+        out[f"res_bilinear{i}"] = np.asarray(Image.fromarray(img).resize((S, S), Image.BILINEAR))    # ADE20K: Dataset.py:1263
         t = torch.from_numpy(res.copy()).permute(2, 0, 1).float().div(255)
         mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(3, 1, 1)
         std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(3, 1, 1)

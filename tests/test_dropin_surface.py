@@ -83,7 +83,7 @@ def test_voc_dataset_device_preprocess_equals_host_pillow_path(tmp_path):
         gt[0, 0] = 255
         Image.fromarray(gt).save(root / "SegmentationClass" / f"{name}.png")
         ids.append(name)
-        table[name] = "[[1: aeroplane, 95%], [12: dog, 80%]]"
+        table[name] = "[1: 'aeroplane', 12: 'dog'], [95%, 80%]"
     (root / "ImageSets/Segmentation/val.txt").write_text("\n".join(ids) + "\n")
     (tmp_path / "GPT4o_classification" / "voc_classification_noboundary.json").write_text(json.dumps(table))
     args = types.SimpleNamespace(home_dir=str(tmp_path), img_size=64, data_type="voc")
@@ -100,3 +100,41 @@ def test_voc_dataset_device_preprocess_equals_host_pillow_path(tmp_path):
             assert np.array_equal(got[j], (x - mean) / std), name
             assert np.array_equal(b["org_images"][j], np.asarray(img))
             assert b["label_trues"][j].dtype == np.float32 and b["label_trues"][j][0, 0] == 0      # 255 -> 0 (PnP.py:908)
+
+
+def test_ade20k_dataset_layout_and_device_preprocess(tmp_path):
+    """`--data_type ade20k` on a tiny fake tree laid out as the reference expects (validation.odgt list,
+    ADEChallengeData2016/{images,annotations}/validation/ADE_val_%08d, GPT table keyed the same way): ids are the
+    zero-stripped number (Dataset.py:1270), the tensor is PIL bilinear resize + ToTensor only (Dataset.py:1263-1275),
+    class names lose their blanks (Load_datasets.py:87)."""
+    import types
+    from PIL import Image
+    from pnp_ovss import datasets
+    (tmp_path / "semantic-segmentation-pytorch-master/data").mkdir(parents=True)
+    (tmp_path / "ADEChallengeData2016/images/validation").mkdir(parents=True)
+    (tmp_path / "ADEChallengeData2016/annotations/validation").mkdir(parents=True)
+    (tmp_path / "GPT4o_classification").mkdir()
+    rng = np.random.default_rng(4)
+    recs, table = [], {}
+    for num, (h, w) in ((7, (60, 80)), (123, (90, 64))):
+        stem = f"ADE_val_{num:08d}"
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(tmp_path / f"ADEChallengeData2016/images/validation/{stem}.jpg", quality=95)
+        Image.fromarray(rng.integers(0, 151, size=(h, w)).astype(np.uint8)).save(tmp_path / f"ADEChallengeData2016/annotations/validation/{stem}.png")
+        recs.append({"fpath_img": f"ADEChallengeData2016/images/validation/{stem}.jpg",
+                     "fpath_segm": f"ADEChallengeData2016/annotations/validation/{stem}.png", "width": w, "height": h})
+        table[stem] = "[45: 'chest of drawers', 3: 'sky', 1: 'wall'], [90%, 85%, 40%]"
+    (tmp_path / "semantic-segmentation-pytorch-master/data/validation.odgt").write_text("\n".join(json.dumps(r) for r in recs) + "\n")
+    (tmp_path / "GPT4o_classification/ade20k_classification_noboundary.json").write_text(json.dumps(table))
+    args = types.SimpleNamespace(home_dir=str(tmp_path), img_size=48, data_type="ade20k")
+    ds = datasets.make_dataset(args, 0, 1)
+    assert len(ds.cats) == 150 and ds.nms[44] == "chestofdrawers" and ds.total_hist.shape == (151, 151)
+    (b,) = list(ds.batches(4))
+    assert sorted(b["img_ids"]) == ["123", "7"]
+    got = b["imgs"].cpu().numpy()
+    for j, img_id in enumerate(b["img_ids"]):
+        stem = "ADE_val_" + img_id.rjust(8, "0")
+        img = Image.open(tmp_path / f"ADEChallengeData2016/images/validation/{stem}.jpg").convert("RGB")
+        x = np.asarray(img.resize((48, 48), Image.BILINEAR), dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
+        assert np.array_equal(got[j], x), img_id
+        best, names, cap = ds.predicted_classes(img_id)
+        assert best == [44, 2] and names == ["chestofdrawers", "sky"] and cap == "A picture of chestofdrawers sky"

@@ -623,6 +623,8 @@ def test_preprocess_images_bit_exact():
         out = hip.preprocess_images([img], S, PP.CLIP_MEAN, PP.CLIP_STD)
         torch.cuda.synchronize()
         assert np.array_equal(out[0].cpu().numpy(), PP.vit_preprocess(img, S)), i
+        out = hip.preprocess_images([img], S, filt="bilinear")                  # ADE20K: bilinear, ToTensor only
+        assert np.array_equal(out[0].cpu().numpy(), PP.ade20k_preprocess(img, S)), i
     rng = np.random.default_rng(5)
     imgs = [rng.integers(0, 256, size=s, dtype=np.uint8) for s in ((375, 500, 3), (500, 333, 3), (336, 400, 3), (120, 90, 3))]
     out = hip.preprocess_images(imgs, 336, PP.CLIP_MEAN, PP.CLIP_STD).cpu().numpy()

@@ -209,6 +209,7 @@ def test_preprocess_matches_pillow_golden(golden_dir):
         img, S = g[f"img{i}"], int(g[f"S{i}"])
         res = PP.resize_bicubic_u8(img, S)
         assert np.array_equal(res, g[f"res{i}"]), i
+        assert np.array_equal(PP.resize_u8(img, S, "bilinear"), g[f"res_bilinear{i}"]), i       # ADE20K input recipe
         t = PP.vit_preprocess(img, S)
         assert t.dtype == np.float32 and t.shape == (3, S, S)
         assert hashlib.sha256(np.ascontiguousarray(t).tobytes()).digest() == g[f"tensor_sha{i}"].tobytes(), i
@@ -218,7 +219,8 @@ def test_preprocess_tables_host_equals_oracle():
     """The host-side table builder the HIP kernel is fed with (pnp_ovss.hip.resample_table) == the oracle's."""
     from pnp_ovss import hip
     from oracle import preprocess_np as PP
-    for n, S in ((500, 336), (375, 336), (64, 96), (336, 336), (1024, 336), (17, 16), (281, 768)):
-        tab, ks = hip.resample_table(n, S)
-        b, kk = PP.resample_coeffs(n, S)
-        assert ks == kk.shape[1] and np.array_equal(tab[:, :2], b) and np.array_equal(tab[:, 2:], kk), (n, S)
+    for filt in ("bicubic", "bilinear"):
+        for n, S in ((500, 336), (375, 336), (64, 96), (336, 336), (1024, 336), (17, 16), (281, 768)):
+            tab, ks = hip.resample_table(n, S, filt)
+            b, kk = PP.resample_coeffs(n, S, filt)
+            assert ks == kk.shape[1] and np.array_equal(tab[:, :2], b) and np.array_equal(tab[:, 2:], kk), (filt, n, S)
