@@ -630,3 +630,54 @@ def test_preprocess_images_bit_exact():
     out = hip.preprocess_images(imgs, 336, PP.CLIP_MEAN, PP.CLIP_STD).cpu().numpy()
     for i, im in enumerate(imgs):
         assert np.array_equal(out[i], PP.vit_preprocess(im, 336)), i
+
+
+@pytest.mark.parametrize("n_sel,n_class,data_type", [(59, 60, "psc"), (80, 81, "voc"), (150, 151, "ade20k")])
+def test_postprocess_many_channels_bit_exact_vs_oracle(n_sel, n_class, data_type):
+    """BASELINE configs 3-5 channel counts (Pascal-Context 59, COCO-Object 80 + background, ADE20K 150) at a small
+    pixel count: one-token-per-class fast path of the merge, no-background rule for >= 3 classes on context datasets,
+    blur and DenseCRF with Kp = 60 / 84 / 152 -- every stage bit-exact against the oracle, CRF label maps included."""
+    cfg = C.blip_itm_small(128)                # P = 8
+    rng = np.random.default_rng(n_sel)
+    sizes = [(72, 96), (64, 64)]
+    B = len(sizes)
+    maps = rng.random((B, n_sel + 4, cfg.grid, cfg.grid), dtype=np.float32) ** 4      # rows: "a picture of" | classes | [SEP]
+    maps[:, n_sel + 3:] = 0
+    best = [list(rng.permutation(n_class - 1)[:n_sel]) for _ in range(B)]
+    best = [[int(v) for v in b] for b in best]
+    has_bg = [OP.has_background("voc" if data_type == "voc" else "psc", n_sel)] * B
+    K = n_sel + int(has_bg[0])
+    rgb = [np.clip(np.repeat(np.repeat(rng.integers(0, 256, size=((h + 7) // 8, (w + 7) // 8, 3)), 8, 0), 8, 1)[:h, :w]
+                   + rng.integers(-6, 7, size=(h, w, 3)), 0, 255).astype(np.uint8) for h, w in sizes]
+    gts = [rng.integers(0, n_class, size=s).astype(np.float32) for s in sizes]
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    e = Engine(cfg, max_batch=2, max_text_len=192, stash_layer=7, bf16=False)      # captions of up to 150 class words
+    e.post_reserve(2, 2 * 96 * 96, 96 * 96, K, 0)
+    plans = [[([i], 1) for i in range(n_sel)]] * B
+    e.post_prepare(sizes, plans, [_lut(b, has_bg[0], K) for b in best], has_bg, rgb=_dev(np.concatenate([r.reshape(-1) for r in rgb])),
+                   gt=_dev(np.concatenate([g.reshape(-1) for g in gts])), want_crf=True)
+    e.merge_tokens(_dev(maps))
+    e.threshold_upsample(0.15, False)
+    e.blur_minmax()
+    torch.cuda.synchronize()
+    blurred = [m.cpu().numpy() for m in e.post_maps("maps")]
+    ref_blur = []
+    for b in range(B):
+        pre = OP.threshold_upsample(maps[b][3:3 + n_sel], sizes[b][0], sizes[b][1], 0.15, False, has_bg[b])     # map[3:-1][:C]
+        rb = np.stack([OP.blurring(pre[k], sizes[b]) for k in range(K)])
+        ref_blur.append(rb)
+        np.testing.assert_array_equal(blurred[b], rb)
+    e.densecrf()
+    hist = torch.zeros(n_class * n_class, device="cuda", dtype=torch.int64)
+    crf_labels = e.split_labels(e.remap_hist(True, n_class, hist))
+    torch.cuda.synchronize()
+    ref_labels = []
+    for b in range(B):
+        lab, q, _ = OP.densecrf(rgb[b], ref_blur[b], want_q=True)
+        ref_l = OP.remap_labels(lab, best[b], has_bg[b])
+        ref_labels.append(ref_l)
+        np.testing.assert_array_equal(crf_labels[b].cpu().numpy().astype(np.float32), ref_l)
+    _, ref_hist = OP.scores(gts, ref_labels, n_class)
+    np.testing.assert_array_equal(hist.cpu().numpy().reshape(n_class, n_class), ref_hist.astype(np.int64))
+    e.close()
