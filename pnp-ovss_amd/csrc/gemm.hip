@@ -450,10 +450,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     if (tile >= ntiles) return;
     int m0, n0;
     stamp(0);
-    if (g.ablate >= 100) {          // experiment (no gain measured): de-phase workgroups so epilogue bursts do not coincide
-        const int steps = ((blockIdx.x >> 3) & 7) * (g.ablate - 100);
-        for (int i = 0; i < steps; i++) __builtin_amdgcn_s_sleep(8);
-    }
     set_tile(tile, m0, n0);
 #pragma unroll
     for (int i = 0; i < NDMA; i++) issue_one(0, i);
@@ -554,7 +550,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         if (tile == (int)blockIdx.x) stamp(2);
 
         __syncthreads();                            // every wave is done reading the last slab: both slots are free
-        if (g.ablate == 30 && tile == (int)blockIdx.x) stamp(1);
         const int em0 = m0, en0 = n0;
         // epilogue operands are requested BEFORE the next tile's first slab: vmcnt is one in-order counter, a
         // wait for a load issued behind the DMA pieces would also wait for those (HBM latency, ~2 us)
@@ -597,7 +592,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < NDMA; i++) issue_one(0, i);
         }
-        if (g.ablate == 31 && tile == (int)blockIdx.x) stamp(1);
 
         if constexpr (EPI == WIDE_TOKCOLS_BF16) {
             // per-row bias and bf16 rounding in the accumulator layout, bf16 staging in two 64-row halves; on the way
@@ -693,7 +687,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                         if (m < g.M && nv) *reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t) = sv[it];
                     }
                 }
-                if (g.ablate == 32 + half && tile == (int)blockIdx.x) stamp(1);
             }
         } else {
             // fp32 residual epilogue, 32-row quarters staged as fp32.  The residual rows of quarter q+1 are
@@ -732,10 +725,9 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                     const int m = em0 + wm * 128 + qd * 32 + it * 4 + (lane >> 4);
                     if (full || (m < g.M && nv)) *reinterpret_cast<f32x4*>(obase + (size_t)(qd * 32 + it * 4) * g.ldo) = v;
                 }
-                if (g.ablate == 32 + qd && tile == (int)blockIdx.x) stamp(1);
             }
         }
-        if (g.ablate < 30 && tile == (int)blockIdx.x) stamp(1);       // diagnostics: first tile's stores issued
+        if (tile == (int)blockIdx.x) stamp(1);     // diagnostics: first tile's epilogue done (stores issued)
         if (next >= ntiles) break;
         tile = next;
     }
