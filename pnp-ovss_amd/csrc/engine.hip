@@ -284,7 +284,7 @@ extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
     KCHK(e, dalloc_t(e, &e->patches, B * e->PP * 768));
     KCHK(e, dalloc(e, &e->x, M * D));
     KCHK(e, dalloc_t(e, &e->xn, M * D));
-    KCHK(e, dalloc_t(e, &e->qk, M * 2 * D));
+    KCHK(e, dalloc_t(e, &e->qk, M * 3 * D));        // bf16 mode: fused q|k|v rows; fp32 mode: q|k rows (v goes to vt)
     KCHK(e, dalloc_t(e, &e->vt, D * ldv, true));
     KCHK(e, dalloc_t(e, &e->ctx, M * D));
     KCHK(e, dalloc_t(e, &e->h1, M * D * c.vit_mlp_ratio));
@@ -600,6 +600,13 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
     for (int l = 0; l < e->c.vit_depth; l++) {
         const VitLayerW& w = e->vit[l];
         KCHK(e, layernorm(bf, e->x, w.n1w, w.n1b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s));
+        if (bf) {   // q | k | v natural in one launch: [M, 3D]; the attention kernel transposes V on its LDS reads
+            GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 3 * D, D);
+            g.bias = w.qkv_b; g.out_t = e->qk; g.ldo_t = 3 * D;
+            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, vit_attention(bf, e->qk, 3 * D, D, (const char*)e->qk + (size_t)2 * D * e->esz, 3 * D, e->Npad, e->ctx, B,
+                                  e->c.vit_heads, N, scale, s));
+        } else {
         {   // q | k  natural: [M, 2D]
             GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 2 * D, D);
             g.bias = w.qkv_b; g.out_t = e->qk; g.ldo_t = 2 * D;
@@ -608,10 +615,10 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
         {   // V^T: [D, B*Npad] = Wv . xn^T, token columns padded per image
             GemmArgs g = G_((const char*)w.qkv_w + (size_t)2 * D * D * e->esz, D, e->xn, D, D, M, D);
             g.bias = w.qkv_b + 2 * D; g.bias_on_rows = 1; g.out_t = e->vt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
-            g.col_perm16 = bf ? 1 : 0;        // the bf16 attention kernel reads V^T in accumulator order
             KCHK(e, gemm_nt(bf, g, s));
         }
         KCHK(e, vit_attention(bf, e->qk, 2 * D, D, e->vt, ldv, e->Npad, e->ctx, B, e->c.vit_heads, N, scale, s));
+        }
         {
             GemmArgs g = G_(e->ctx, D, w.proj_w, D, M, D, D);
             g.bias = w.proj_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;

@@ -239,14 +239,16 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qk,
 
 // ------------------------------------------------------------------------------------------
 // bf16 ViT self-attention, second generation.  One wave = 32 queries of one (image, head) with
-// v_mfma_f32_32x32x16_bf16; a workgroup is up to 8 such waves sharing the K / V^T tiles, which arrive by
-// LDS-DMA into a two-slot ring (one s_barrier per 64-key tile).  Against the first kernel (16 queries
-// per wave, 16x16 tiles, register-staged tiles) this halves the LDS fragment bytes per FLOP and per
-// score element spends one fma + one exp2 + one add + half a max3 + half a cvt:
+// v_mfma_f32_32x32x16_bf16; a workgroup is up to 8 such waves sharing the K / V tiles, which arrive by
+// LDS-DMA into a two-slot ring (one s_barrier per 64-key tile) straight from the fused q|k|v rows.
+// Against the first kernel (16 queries per wave, 16x16 tiles, register-staged tiles, V^T from its own GEMM)
+// this halves the LDS fragment bytes per FLOP and per score element spends one fma + one exp2 + one add
+// + half a max3 + half a cvt:
 //   S^T = K.Q^T (keys on accumulator rows, the query on the lane column) -> running max per lane pair
 //   -> p = exp2(s c - m c), c = scale log2 e -> O^T += V^T.P^T with P taken from the S^T registers in
-//   "accumulator order" (the V^T fragment is read with the same key permutation).
-// The O rescale is skipped when no lane of the wave raised its maximum.
+//   "accumulator order"; the V^T fragment comes out of the row-major V tile through the transposing LDS
+//   read ds_read_b64_tr_b16 (two 4-key blocks per lane = the same key order P has), so no V^T is ever
+//   materialised in memory.
 __global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict__ qk, int ld_qk, int D,
                                                          const bf16* __restrict__ vt, int ld_vt, int Npad,
                                                          bf16* __restrict__ ctx, int N, float scale, int nqw) {
@@ -272,21 +274,16 @@ __global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict_
 
     // DMA: 16 pieces of 8 rows per tile pair (8 K + 8 V^T), dealt round-robin to the waves
     const char* kbase = reinterpret_cast<const char*>(qk + row0 * ld_qk + D + h * 64);
-    const char* vbase = reinterpret_cast<const char*>(vt + (size_t)(h * 64) * ld_vt + (size_t)b * Npad);
+    const char* vbase = reinterpret_cast<const char*>(vt + row0 * ld_vt + h * 64);      // V rows of this image (natural layout)
     const int prow = lane >> 3, pc = lane & 7;
     auto issue_tile = [&](int t) {
         char* dst = ring[t & 1];
         for (int p = wave; p < 16; p += nwaves) {
             const int row = (p & 7) * 8 + prow;
             const int sc = pc ^ ((row >> 1) & 7);
-            const char* src;
-            if (p < 8) {
-                int key = t * 64 + row;
-                key = key < N ? key : N - 1;
-                src = kbase + (size_t)key * ld_qk * 2 + sc * 16;
-            } else {
-                src = vbase + (size_t)row * ld_vt * 2 + (size_t)t * 128 + sc * 16;
-            }
+            int key = t * 64 + row;
+            key = key < N ? key : N - 1;             // keys >= N get p = 0 (masked scores), their V rows are finite copies
+            const char* src = p < 8 ? kbase + (size_t)key * ld_qk * 2 + sc * 16 : vbase + (size_t)key * ld_vt * 2 + sc * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
         }
@@ -361,14 +358,24 @@ __global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict_
                 fp[kt * 2 + (e >> 3)][e & 7] = (bf16)p;
             }
         // O^T += V^T . P^T : k16 step j covers keys 16j .. 16j+15, lane half hi holds keys 16j + 4hi + (0..3) and
-        // 16j + 8 + 4hi + (0..3) (accumulator order)
+        // 16j + 8 + 4hi + (0..3) (accumulator order).  Transposing read: the 16 lanes of a group fetch a 4-key x 16-d
+        // block (lane 4q+p supplies the address of key q, d 4p..4p+3) and lane i receives d = i of the 4 keys.
+        const int grp_d = ((lane >> 4) & 1) * 16, tq = (lane >> 2) & 3, tp = lane & 3;
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
             for (int dt = 0; dt < 2; dt++) {
-                // V^T arrives with the two middle 4-token groups of every 16 swapped (GEMM epilogue, col_perm16), so
-                // the 8 keys of lane half hi are one 16-byte chunk
-                const bf16x8 fv = *reinterpret_cast<const bf16x8*>(Vs + (dt * 32 + l32) * ROWB + (((2 * j + hi) ^ sw) << 4));
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                s16x4 part[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int key = 16 * j + 8 * u + 4 * hi + tq;                       // row of the V tile
+                    const int col = dt * 32 + grp_d + 4 * tp;                           // first of 4 d's
+                    const char* a = Vs + key * ROWB + ((((col >> 3)) ^ ((key >> 1) & 7)) << 4) + (col & 7) * 2;
+                    part[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+                }
+                const bf16x4 lo = __builtin_bit_cast(bf16x4, part[0]), hh = __builtin_bit_cast(bf16x4, part[1]);
+                const bf16x8 fv = {lo[0], lo[1], lo[2], lo[3], hh[0], hh[1], hh[2], hh[3]};
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv, fp[j], o[dt], 0, 0, 0);
             }
     }
@@ -400,7 +407,7 @@ static int vit_attn_t(const void* qk, int ld_qk, int D, const void* vt, int ld_v
 int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
                   int H, int N, float scale, hipStream_t s) {
     if (D != H * 64 || Npad % 64 || Npad < N) return PNP_ERR_ARG;
-    if (bf) {       // vt must come from the GEMM's col_perm16 epilogue (middle 4-token groups of every 16 swapped)
+    if (bf) {       // bf16: `vt` is V in the NATURAL layout [B*N, ld_vt] (the fused q|k|v rows), transposed on the LDS read
         const int nqw = (N + 31) / 32;                          // 32-query waves per (image, head)
         static const int max_wpb = getenv("PNP_ATTN_WPB") ? atoi(getenv("PNP_ATTN_WPB")) : 8;
         const int nblk = (nqw + max_wpb - 1) / max_wpb, wpb = (nqw + nblk - 1) / nblk;
