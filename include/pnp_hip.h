@@ -179,10 +179,10 @@ int pnp_op_gemm_tokcols(int32_t bf16, const void* d_A, int32_t lda, const void* 
                         int32_t K, const float* d_bias_rows, void* d_out_t, int32_t ldo_t, int32_t col_div,
                         int32_t col_pad, void* stream);
 /* ViT self-attention of one block (B/vit.py:93-117): ctx = softmax(q k^T * scale) v per (image, head), head_dim 64.
- * d_qk [B*N, ld_qk]: q of head h at column h*64, k at column D + h*64; d_vt [D, ld_vt]: V^T, row h*64+d, column
- * b*n_pad + token (n_pad a multiple of 64, pad columns zero); d_ctx [B*N, D].  In bf16 mode V^T is expected in the
- * "accumulator order" the transposed-V GEMM epilogue writes: inside every aligned group of 16 tokens of an image the
- * 4-token groups 1 and 2 trade places. */
+ * d_qk [B*N, ld_qk]: q of head h at column h*64, k at column D + h*64; d_ctx [B*N, D].
+ * fp32 mode: d_vt [D, ld_vt] = V^T, row h*64+d, column b*n_pad + token (n_pad a multiple of 64, pad columns zero).
+ * bf16 mode: d_vt [B*N, ld_vt] = V in the natural layout, head h at column h*64 (e.g. the v third of fused q|k|v
+ * rows); it is transposed by the kernel's LDS reads and n_pad is not used. */
 int pnp_op_vit_attention(int32_t bf16, const void* d_qk, int32_t ld_qk, int32_t D, const void* d_vt, int32_t ld_vt,
                          int32_t n_pad, void* d_ctx, int32_t B, int32_t heads, int32_t N, float scale, void* stream);
 int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,

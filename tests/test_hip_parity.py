@@ -217,7 +217,7 @@ def test_cross_attention_operator(bf16, N, L):
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("N", [17, 197, 442, 577, 2305])
 def test_vit_attention_operator(bf16, N):
-    """ViT self-attention kernels (fp32: 16-query waves; bf16: 32-query waves reading V^T in accumulator order)
+    """ViT self-attention kernels (fp32: 16-query waves, V^T operand; bf16: 32-query waves, V transposed on the LDS read)
     against softmax(q k^T / 8) v in fp64.  Token counts cover a single ragged key tile, the 224 / 336 / 384 / 768
     pixel geometries and idle waves in the last workgroup.  f32: 2e-5; bf16 operands and output: 2e-2."""
     from pnp_ovss.hip import load_library
@@ -230,17 +230,18 @@ def test_vit_attention_operator(bf16, N):
     q = torch.randn(B, N, D, generator=g).to(tdt)
     k = torch.randn(B, N, D, generator=g).to(tdt)
     v = torch.randn(B, N, D, generator=g).to(tdt)
-    qk = torch.cat([q, k], dim=-1).reshape(B * N, 2 * D).contiguous().cuda()
-    vt = torch.zeros(D, B, Npad, dtype=tdt)
-    cols = torch.arange(N)
-    if bf16:                                        # 4-token groups 1 and 2 of every 16 trade places
-        grp = (cols >> 2) & 3
-        cols = torch.where((grp == 1) | (grp == 2), cols ^ 12, cols)
-    vt[:, :, cols] = v.permute(2, 0, 1)
-    vt = vt.reshape(D, B * Npad).contiguous().cuda()
     ctx = torch.zeros(B * N, D, dtype=tdt, device="cuda")
-    assert lib.pnp_op_vit_attention(1 if bf16 else 0, qk.data_ptr(), 2 * D, D, vt.data_ptr(), B * Npad, Npad, ctx.data_ptr(),
-                                    B, heads, N, 0.125, None) == 0
+    if bf16:                                        # fused q | k | v rows, V read in place (natural layout)
+        qkv = torch.cat([q, k, v], dim=-1).reshape(B * N, 3 * D).contiguous().cuda()
+        assert lib.pnp_op_vit_attention(1, qkv.data_ptr(), 3 * D, D, qkv.data_ptr() + 2 * D * 2, 3 * D, Npad, ctx.data_ptr(),
+                                        B, heads, N, 0.125, None) == 0
+    else:                                           # q | k rows + V^T with per-image padded token columns
+        qk = torch.cat([q, k], dim=-1).reshape(B * N, 2 * D).contiguous().cuda()
+        vt = torch.zeros(D, B, Npad, dtype=tdt)
+        vt[:, :, :N] = v.permute(2, 0, 1)
+        vt = vt.reshape(D, B * Npad).contiguous().cuda()
+        assert lib.pnp_op_vit_attention(0, qk.data_ptr(), 2 * D, D, vt.data_ptr(), B * Npad, Npad, ctx.data_ptr(),
+                                        B, heads, N, 0.125, None) == 0
     torch.cuda.synchronize()
     f = lambda a: a.double().view(B, N, heads, 64).permute(0, 2, 1, 3)
     P = (f(q) @ f(k).transpose(-1, -2) * 0.125).softmax(-1)
