@@ -24,8 +24,6 @@ struct GemmArgs {
     int ld_aux = 0;
     int row_div = 0;               // >0: patch rows -> token rows b*(row_div+1)+1+p, resid = pos_embed
     int col_div = 0, col_pad = 0;  // >0: output column n -> (n / col_div) * col_pad + n % col_div
-    int col_perm16 = 0;            // with col_div: swap the two middle 4-column groups of every 16 output columns of an image
-                                   // ("accumulator order" for the 32x32 attention kernel); wide kernel only
     unsigned long long* stamps = nullptr;   // diagnostics (PNP_GEMM_STAMPS): per-workgroup clock stamps, 8 per block
     int ablate = 0;                // timing experiments only (PNP_GEMM_ABLATE): 1 = no steady-state DMA, 2 = no MFMA
 };

@@ -378,7 +378,7 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 // wait ever sits behind a store; epilogues are compile-time variants (no generic branches).
 
 // EPI: 0 = +bias -> bf16 | 1 = +bias, GELU -> bf16 | 2 = +bias +residual -> fp32 |
-//      3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (transposed K / V projections)
+//      3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (transposed cross-attention K / V)
 enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3 };
 constexpr int kWideStageRow = 68;                                  // floats per staged row (64 + 4 pad)
 constexpr int kWideStageBytes = 8 * 32 * kWideStageRow * 4;        // 8 waves x 32 rows
@@ -606,10 +606,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
             if (g.col_div > 0) {
                 const int b = tok / g.col_div;
                 int tl = tok - b * g.col_div;
-                if (g.col_perm16) {                 // 4-column groups 1 and 2 of every 16 trade places
-                    const int grp = (tl >> 2) & 3;
-                    if (grp == 1 || grp == 2) tl ^= 12;
-                }
                 ocol = (size_t)b * g.col_pad + tl;
             }
             bf16* const ocolp = reinterpret_cast<bf16*>(g.out_t) + ocol;
@@ -741,7 +737,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 // remaps, per-row bias, stashes, dual outputs) stays on the generic kernels
 static int wide_epilogue_kind(const GemmArgs& g) {
     if (g.aux || g.row_div) return -1;
-    if (g.col_perm16 && g.col_div <= 0) return -1;
     if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_t && !g.out_f32 && (g.bias_on_rows || !g.bias) && (g.col_div > 0 || g.bias_on_rows))
         return WIDE_TOKCOLS_BF16;
     if (g.col_div || g.bias_on_rows || (g.Nvalid & 3)) return -1;
@@ -926,7 +921,7 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     g.Nvalid = g.N;
     // small problems (text side: M = B*L rows) use 64x64 tiles to fill more CUs
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const bool small = tiles128 < 192 && !g.col_perm16;       // col_perm16 exists in the wide kernel's epilogue only
+    const bool small = tiles128 < 192;
     if (small) {
         // text side (M = B*L rows): 64 x 64 tiles, 4 waves of 32 x 32, 3-slot DMA ring -- the deep
         // prefetch matters more than tile efficiency for these latency-bound launches
@@ -969,8 +964,7 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     const bool big_k = g.K >= 2048 && g.Nvalid >= 512;
     const int wide = dtype_bf16 ? wide_epilogue_kind(g) : -1;
     const long tiles256 = (long)((g.M + 255) / 256) * ((g.Nvalid + 255) / 256);
-    if (g.col_perm16 && wide != WIDE_TOKCOLS_BF16) return PNP_ERR_ARG;     // only that epilogue implements it
-    if (wide >= 0 && (variant == 4 || g.col_perm16 || (variant == 0 && tiles256 >= 128))) {
+    if (wide >= 0 && (variant == 4 || (variant == 0 && tiles256 >= 128))) {
         g.N = (g.Nvalid + 255) / 256 * 256;
         r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16>(g, s)
             : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16>(g, s)
