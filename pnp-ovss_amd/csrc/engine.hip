@@ -1084,7 +1084,7 @@ extern "C" int pnp_densecrf(pnp_engine* e, int32_t iters, float pos_w, float pos
         return fail(e, PNP_ERR_ARG, "lattices are built for sxy=3 / sxy=50, srgb=5 (PnP.py:1036-1041)");
     hipStream_t s = (hipStream_t)stream;
     const float* maps = p.maps_in_2 ? p.maps2 : p.maps;
-    KCHK(e, unary_from_maps(maps, p.d_desc, p.unary, p.B, p.maxHW, s));
+    KCHK(e, unary_from_maps(maps, p.d_desc, p.unary, p.B, p.maxHW, p.maxKp, s));
     for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
         const int n = std::min(p.chunk, p.B - c0);
         KCHK(e, crf_update(p.lat[0], p.lat[1], p.d_desc, c0, n, p.vga, p.va, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 0,

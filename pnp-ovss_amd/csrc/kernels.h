@@ -77,7 +77,7 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
               int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s);
 int preprocess_images(const uint8_t* rgb, const void* desc, int B, int S, int max_H, const int32_t* coef, uint8_t* tmp,
                       const float* mean3, const float* std3, float* out, hipStream_t s);
-int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, hipStream_t s);
+int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, hipStream_t s);
 int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int lut_stride, uint8_t* labels,
                  const size_t* label_off, int pixel_major, int B, int maxHW, hipStream_t s);
 int confusion_hist(const uint8_t* labels, const float* gt, const PostDesc* desc, const size_t* label_off,

@@ -480,27 +480,44 @@ int preprocess_images(const uint8_t* rgb, const void* desc, int B, int S, int ma
 // ------------------------------------------------------------------------------------------
 // softmax over channels + unary = -log(clip(p, 1e-5, 1)), written pixel-major [n][K]
 // (densecrf's value layout).  include/pnp_math.h defines exp/log bit-exactly for host and device.
-__global__ void unary_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc, float* __restrict__ unary) {
+__global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc,
+                                                    float* __restrict__ unary) {
+    // tile of 256 pixels: channel-major reads (coalesced along pixels), results parked in LDS [pixel][Kp + 1], then
+    // written as whole 16-byte chunks of the pixel-major rows (the per-thread row writes were 4 bytes at a 96-byte stride)
+    extern __shared__ __attribute__((aligned(16))) float utile[];
     const int b = blockIdx.y;
     const PostDesc d = desc[b];
-    const int n = d.H * d.W, K = d.K, Kp = d.Kp;
+    const int n = d.H * d.W, K = d.K, Kp = d.Kp, K4 = Kp >> 2, ldt = Kp + 1;
     const float* m = maps + d.off;
-    float* u = unary + d.qoff;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float mx = m[i];
-        for (int k = 1; k < K; k++) {
-            const float v = m[(size_t)k * n + i];
-            if (v > mx || v != v) mx = v;
+    f32x4* u4 = reinterpret_cast<f32x4*>(unary + d.qoff);
+    const int tid = threadIdx.x;
+    for (int p0 = blockIdx.x * 256; p0 < n; p0 += gridDim.x * 256) {
+        const int np = (n - p0) < 256 ? (n - p0) : 256;
+        if (tid < np) {
+            const int i = p0 + tid;
+            float mx = m[i];
+            for (int k = 1; k < K; k++) {
+                const float v = m[(size_t)k * n + i];
+                if (v > mx || v != v) mx = v;
+            }
+            float s = 0.f;
+            for (int k = 0; k < K; k++) s = __fadd_rn(s, pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)));
+            float* row = utile + tid * ldt;
+            for (int k = 0; k < K; k++) {
+                float p = __fdiv_rn(pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)), s);
+                if (p < 1e-5f) p = 1e-5f;
+                else if (p > 1.0f) p = 1.0f;
+                row[k] = -pnp_logf(p);
+            }
+            for (int k = K; k < Kp; k++) row[k] = 0.f;
         }
-        float s = 0.f;
-        for (int k = 0; k < K; k++) s = __fadd_rn(s, pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)));
-        for (int k = 0; k < K; k++) {
-            float p = __fdiv_rn(pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)), s);
-            if (p < 1e-5f) p = 1e-5f;
-            else if (p > 1.0f) p = 1.0f;
-            u[(size_t)i * Kp + k] = -pnp_logf(p);
+        __syncthreads();
+        for (int item = tid; item < np * K4; item += 256) {
+            const int pl = item / K4, c = item - pl * K4;
+            const float* r = utile + pl * ldt + 4 * c;
+            u4[(size_t)(p0 + pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
         }
-        for (int k = K; k < Kp; k++) u[(size_t)i * Kp + k] = 0.f;
+        __syncthreads();
     }
 }
 
@@ -516,9 +533,22 @@ __global__ void argmax_kernel(const float* __restrict__ q, const PostDesc* __res
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int best = 0;
         float bv = pixel_major ? p[(size_t)i * Kp] : p[i];
-        for (int k = 1; k < K; k++) {
-            const float v = pixel_major ? p[(size_t)i * Kp + k] : p[(size_t)k * n + i];
-            if (bv == bv && (v > bv || v != v)) { best = k; bv = v; }
+        if (pixel_major) {                          // rows are Kp = 4 * ceil(K / 4) floats, 16-byte aligned: vector loads
+            const f32x4* row = reinterpret_cast<const f32x4*>(p + (size_t)i * Kp);
+            for (int c = 0; c < Kp / 4; c++) {
+                const f32x4 v4 = row[c];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int k = c * 4 + j;
+                    const float v = v4[j];
+                    if (k >= 1 && k < K && bv == bv && (v > bv || v != v)) { best = k; bv = v; }
+                }
+            }
+        } else {
+            for (int k = 1; k < K; k++) {
+                const float v = p[(size_t)k * n + i];
+                if (bv == bv && (v > bv || v != v)) { best = k; bv = v; }
+            }
         }
         labels[label_off[b] + i] = (uint8_t)lut[b * lut_stride + best];
     }
@@ -628,9 +658,17 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
     return ok();
 }
 
-int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, hipStream_t s) {
+int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, hipStream_t s) {
     const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
-    hipLaunchKernelGGL(unary_kernel, dim3(nb, B), dim3(256), 0, s, maps, desc, unary);
+    const size_t smem = (size_t)256 * (max_kp + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && smem > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(unary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+            hipSuccess)
+            return PNP_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(unary_kernel, dim3(nb, B), dim3(256), smem, s, maps, desc, unary);
     return ok();
 }
 
