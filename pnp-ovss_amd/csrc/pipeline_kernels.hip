@@ -206,11 +206,19 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ m
     float mn = INFINITY, mx = -INFINITY;
     bool nan = false;
     const int n = d.H * d.W;
-    for (int p = tid; p < n; p += 256) {
-        const float v = m[p];
-        nan |= (v != v);
-        mn = fminf(mn, v);
-        mx = fmaxf(mx, v);
+    for (int p0 = tid; p0 < n; p0 += 8 * 256) {               // eight independent loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int p = p0 + u * 256;
+            v[u] = p < n ? m[p] : m[p0];                        // out-of-range slots repeat an in-range sample
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            nan |= (v[u] != v[u]);
+            mn = fminf(mn, v[u]);
+            mx = fmaxf(mx, v[u]);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, o, 64));
