@@ -1,5 +1,5 @@
-"""One ViT-L block's five dense launches at the bench shape (35 images x 442 tokens), replayed REPS times:
-qk (N=2048), transposed V (token columns), proj (+residual), fc1 (+GELU), fc2 (+residual).  Used under
+"""One ViT-L block's four dense launches at the bench shape (35 images x 442 tokens), replayed REPS times:
+fused q|k|v (N=3072), proj (+residual), fc1 (+GELU), fc2 (+residual).  Used under
 `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE --kernel-include-regex gemm_nt_wide` for roofline.traffic."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,12 +17,11 @@ wqkv = (0.02 * torch.randn(3 * D, D, device="cuda")).to(bf); wproj = (0.02 * tor
 wfc1 = (0.02 * torch.randn(F, D, device="cuda")).to(bf); wfc2 = (0.02 * torch.randn(D, F, device="cuda")).to(bf)
 bq = torch.randn(3 * D, device="cuda"); bp = torch.randn(D, device="cuda"); b1 = torch.randn(F, device="cuda"); b2 = torch.randn(D, device="cuda")
 x = torch.randn(M, D, device="cuda")
-qk = torch.empty(M, 2 * D, device="cuda", dtype=bf); vt = torch.zeros(D, B * Npad, device="cuda", dtype=bf)
+qkv = torch.empty(M, 3 * D, device="cuda", dtype=bf)
 h1o = torch.empty(M, F, device="cuda", dtype=bf)
 p = lambda t: t.data_ptr()
 for _ in range(REPS):
-    assert lib.pnp_op_gemm_ex(1, p(xn), D, p(wqkv), D, M, 2 * D, D, p(bq), None, 0, None, 0, p(qk), 2 * D, 0, None) == 0
-    assert lib.pnp_op_gemm_tokcols(1, p(wqkv) + 2 * D * D * 2, D, p(xn), D, D, M, D, p(bq) + 2 * D * 4, p(vt), B * Npad, N, Npad, None) == 0
+    assert lib.pnp_op_gemm_ex(1, p(xn), D, p(wqkv), D, M, 3 * D, D, p(bq), None, 0, None, 0, p(qkv), 3 * D, 0, None) == 0
     assert lib.pnp_op_gemm_ex(1, p(ctx), D, p(wproj), D, M, D, D, p(bp), p(x), D, p(x), D, None, 0, 0, None) == 0
     assert lib.pnp_op_gemm_ex(1, p(xn), D, p(wfc1), D, M, F, D, p(b1), None, 0, None, 0, p(h1o), F, 1, None) == 0
     assert lib.pnp_op_gemm_ex(1, p(h1), F, p(wfc2), F, M, D, F, p(b2), p(x), D, p(x), D, None, 0, 0, None) == 0
