@@ -517,6 +517,23 @@ __global__ void renumber_entries_kernel(const int* __restrict__ rank, size_t n, 
         offset[i] = rank[offset[i]];
 }
 
+// ---- contributor lists in lattice-id order.  The key sort leaves each point's contributor segment where its KEY
+// sorted; after the spatial renumbering consecutive lattice ids own segments scattered over the whole list.  The
+// segments are moved (each keeps its ascending-pixel order) so that id order = list order: the splat then walks the
+// list front to back, and a range of lattice points is a contiguous range of contributors.
+__global__ void seg_len_kernel(const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int M, int* __restrict__ len) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) len[i] = seg_hi[i] - seg_lo[i];
+}
+__global__ void move_segments_kernel(const uint32_t* __restrict__ vals, const int* __restrict__ new_start, int M,
+                                     int* __restrict__ seg_lo, int* __restrict__ seg_hi, uint32_t* __restrict__ vals2) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const int a = seg_lo[i], n = seg_hi[i] - a, d = new_start[i];
+        for (int j = 0; j < n; j++) vals2[d + j] = vals[a + j];
+        seg_lo[i] = d;
+        seg_hi[i] = d + n;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 static inline int ok() { return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP; }
 
@@ -581,6 +598,14 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     hipLaunchKernelGGL(renumber_points_kernel, dim3(1024), dim3(256), 0, s, rank, L.seg_start, n1k, n2k, L.cap, M, D + 1,
                        L.seg_lo, L.seg_hi, L.n1, L.n2);
     hipLaunchKernelGGL(renumber_entries_kernel, dim3(2048), dim3(256), 0, s, rank, ent_total, L.offset);
+    // contributor segments into lattice-id order (scratch: keys_a = lengths, incl = new starts, keys_b = moved list)
+    int* len = reinterpret_cast<int*>(keys_a);
+    uint32_t* vals2 = reinterpret_cast<uint32_t*>(keys_b);
+    hipLaunchKernelGGL(seg_len_kernel, dim3(1024), dim3(256), 0, s, L.seg_lo, L.seg_hi, M, len);
+    tb = temp_bytes;
+    if (hipcub::DeviceScan::ExclusiveSum(temp, tb, len, incl, M, s) != hipSuccess) return PNP_ERR_HIP;
+    hipLaunchKernelGGL(move_segments_kernel, dim3(2048), dim3(256), 0, s, L.vals, incl, M, L.seg_lo, L.seg_hi, vals2);
+    if (hipMemcpyAsync(L.vals, vals2, ent_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return PNP_ERR_HIP;
     return ok();
 }
 
