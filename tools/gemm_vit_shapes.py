@@ -1,4 +1,4 @@
-"""Scratch probe: wide-tile GEMM variants on the ViT-L shapes (run with PNP_GEMM_VARIANT=0/4)."""
+"""Throughput and error of the ViT-L block GEMM shapes at the bench batch (PNP_GEMM_VARIANT forces a kernel)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "pnp-ovss_amd"))
