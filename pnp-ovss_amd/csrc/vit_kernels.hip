@@ -96,8 +96,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (y) reinterpret_cast<f32x4*>(y + (size_t)row * D)[c] = o;
         if (yt) {
             T* p = yt + (size_t)row * D + c * 4;
-#pragma unroll
-            for (int e = 0; e < 4; e++) p[e] = from_f32<T>(o[e]);
+            if constexpr (sizeof(T) == 2) {          // one 8-byte store per lane: 512 contiguous bytes per wave
+                const bf16x4 pk = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+                *reinterpret_cast<bf16x4*>(p) = pk;
+            } else {
+                *reinterpret_cast<f32x4*>(p) = o;
+            }
         }
     }
 }
