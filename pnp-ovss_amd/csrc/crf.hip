@@ -297,24 +297,27 @@ __global__ void crf_norm_kernel(const CrfLattice L, const PostDesc* __restrict__
 // (round-robin dispatch; a speed assumption only), so each XCD is given whole images (b = xcd,
 // xcd + 8, ...) and sweeps them one after another: the ~10 MB value rows of the image an XCD is
 // working on are re-read (neighbour / contributor gathers) out of L2 / Infinity Cache instead of HBM.
-// Inside an image 8 lanes share one lattice point (one 16-byte channel chunk each).
+// Inside an image LPP lanes share one lattice point (one 16-byte channel chunk each); LPP = 8, 16 or 32 is the
+// smallest that covers the widest row of the batch, so the contributor list of a point is walked once
+// (with LPP = 8 a 36-float row walked it twice: +43 % on the whole mean-field pass).
 //
 // splat: val[id] = sum over the lattice point's contributors (ascending pixel) of bary * (Q * norm)
-template <int D1>
+template <int D1, int LPP>
 __global__ __launch_bounds__(256) void crf_splat4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
                                                          const float* __restrict__ Q, const float* __restrict__ norm,
                                                          float* __restrict__ val, int img0, int nimg) {
+    constexpr int PPB = 256 / LPP;                       // lattice points per workgroup pass
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int c0 = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int c0 = threadIdx.x & (LPP - 1), pl = threadIdx.x / LPP;
     for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
         const PostDesc im = imgs[b];
         const int K4 = im.Kp >> 2;
         const int lo = L.idbase[b], hi = L.idbase[b + 1];
         const f32x4* Q4 = reinterpret_cast<const f32x4*>(Q + im.qoff);
         f32x4* V4 = reinterpret_cast<f32x4*>(val + im.voff[L.which]);
-        for (int idl = slot * 32 + pl; idl < hi - lo; idl += bpx * 32) {
+        for (int idl = slot * PPB + pl; idl < hi - lo; idl += bpx * PPB) {
             const int e0 = L.seg_lo[lo + idl], e1 = L.seg_hi[lo + idl];
-            for (int c = c0; c < K4; c += 8) {
+            for (int c = c0; c < K4; c += LPP) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
                 for (int e = e0; e < e1; e += 4) {
                     // issue up to four independent gathers before the ordered accumulation
@@ -632,13 +635,21 @@ int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max
 
 // lattice(norm * Q) for images [img0, img0+nimg): splat + (d+1) blurs.  Returns the buffer holding the result.
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
-               float* va, float* vb, const float** result, hipStream_t s) {
+               float* va, float* vb, const float** result, int max_kp, hipStream_t s) {
     const int D = L.D1 - 1;
     const int nb = 8 * 256;                                 // 8 XCD groups x 256 resident workgroups per XCD
-    if (L.D1 == 3)
-        hipLaunchKernelGGL((crf_splat4_kernel<3>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, nimg);
-    else
-        hipLaunchKernelGGL((crf_splat4_kernel<6>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, nimg);
+    const int k4 = (max_kp + 3) / 4;
+#define PNP_SPLAT(D1_, LPP_) hipLaunchKernelGGL((crf_splat4_kernel<D1_, LPP_>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, nimg)
+    if (L.D1 == 3) {
+        if (k4 <= 8) PNP_SPLAT(3, 8);
+        else if (k4 <= 16) PNP_SPLAT(3, 16);
+        else PNP_SPLAT(3, 32);
+    } else {
+        if (k4 <= 8) PNP_SPLAT(6, 8);
+        else if (k4 <= 16) PNP_SPLAT(6, 16);
+        else PNP_SPLAT(6, 32);
+    }
+#undef PNP_SPLAT
     float* src = va;
     float* dst = vb;
     for (int j = 0; j <= D; j++) {

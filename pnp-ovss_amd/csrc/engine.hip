@@ -1091,8 +1091,8 @@ extern "C" int pnp_densecrf(pnp_engine* e, int32_t iters, float pos_w, float pos
                            p.maxHW, p.Kpmax, s));
         for (int it = 0; it < iters; it++) {
             const float *rg = nullptr, *rb = nullptr;
-            KCHK(e, crf_filter(p.lat[0], p.d_desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, s));
-            KCHK(e, crf_filter(p.lat[1], p.d_desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, s));
+            KCHK(e, crf_filter(p.lat[0], p.d_desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, p.Kpmax, s));
+            KCHK(e, crf_filter(p.lat[1], p.d_desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, p.Kpmax, s));
             KCHK(e, crf_update(p.lat[0], p.lat[1], p.d_desc, c0, n, rg, rb, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 1,
                                p.maxHW, p.Kpmax, s));
         }

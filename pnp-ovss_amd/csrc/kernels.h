@@ -92,7 +92,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
 int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, float* va, float* vb,
                      float* norm_out, hipStream_t s);
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
-               float* va, float* vb, const float** result, hipStream_t s);
+               float* va, float* vb, const float** result, int max_kp, hipStream_t s);
 int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
                const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
                float w_b, int pairwise, int max_pixels, int max_kp, hipStream_t s);
