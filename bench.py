@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--crf-chunk", type=int, default=0)
     ap.add_argument("--skip-1drop", action="store_true", help="PnPc.py behaviour (COCO driver): N-drop branch only")
+    ap.add_argument("--separate-crf", action="store_true", help="run the 1-drop and N-drop DenseCRF as two passes (default: paired)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
                     help="software-pipeline batches over two HIP streams (drop loop of batch i+1 beside the post-process "
@@ -147,9 +148,13 @@ def main():
         with torch.cuda.stream(s_post):
             s_post.wait_event(ev)
             e.post_prepare(sizes, plans, luts, [True] * B, rgb=d_rgb, gt=d_gt, want_crf=True)
-            if not a.skip_1drop:
+            if a.skip_1drop:
+                state["ln"] = e.postprocess(agg, THRESH, False, "blur+crf", 21, histn)
+            elif a.separate_crf:
                 state["l1"] = e.postprocess(g0, THRESH, True, "blur+crf", 21, hist1)
-            state["ln"] = e.postprocess(agg, THRESH, False, "blur+crf", 21, histn)
+                state["ln"] = e.postprocess(agg, THRESH, False, "blur+crf", 21, histn)
+            else:       # both branches in one DenseCRF run (two channel groups per row; identical results)
+                state["l1"], state["ln"] = e.postprocess_pair(g0, agg, THRESH, 21, hist1, histn)
         keep.append((g0, agg))
 
     def run(n):

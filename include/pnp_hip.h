@@ -136,6 +136,13 @@ int pnp_remap_hist(pnp_engine* e, int32_t from_crf, uint8_t* d_labels, unsigned 
 int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T, float threshold, int32_t scale01, int32_t mode,
                     uint8_t* d_labels, unsigned long long* d_hist, int32_t n_class, void* stream);
 
+/* Both post-processing branches of a batch -- 1-drop (PnP.py:348-403, with Scale_0_1) and N-drop (PnP.py:424-481) --
+ * with "blur+crf" in one DenseCRF run: the two problems share the image's lattices, so they are iterated side by side
+ * (two channel groups per row).  Results equal two pnp_postprocess(..., mode 3, ...) calls bit for bit. */
+int pnp_postprocess_pair(pnp_engine* e, const float* d_gradcam_1drop, const float* d_gradcam_ndrop, int32_t T, float threshold,
+                         uint8_t* d_labels_1drop, unsigned long long* d_hist_1drop, uint8_t* d_labels_ndrop,
+                         unsigned long long* d_hist_ndrop, int32_t n_class, void* stream);
+
 /* ---- input side ("next" row: the tensors the reference's datasets hand to the model) -------
  * Dataset.py:434-443: transforms.Resize((S, S), BICUBIC) on the PIL image -> ToTensor -> Normalize(mean, std).
  * Pillow's 8-bit two-pass resampler (src/libImaging/Resample.c) in integer arithmetic, bit-exact: per axis and

@@ -459,20 +459,22 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
             }
             __syncthreads();
             if (tid < np) {
-                float* row = tile + tid * ldt;
-                float m = row[0];
-                for (int k = 1; k < K; k++) {
-                    const float v = row[k];
-                    if (v > m || v != v) m = v;
+                for (int grp = 0; grp < im.G; grp++) {              // one softmax per channel group
+                    float* row = tile + tid * ldt + grp * im.Kg;
+                    float m = row[0];
+                    for (int k = 1; k < K; k++) {
+                        const float v = row[k];
+                        if (v > m || v != v) m = v;
+                    }
+                    float s = 0.f;
+                    for (int k = 0; k < K; k++) {
+                        const float e = pnp_expf(__fsub_rn(row[k], m));
+                        row[k] = e;
+                        s = __fadd_rn(s, e);
+                    }
+                    for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
+                    for (int k = K; k < im.Kg; k++) row[k] = 0.f;
                 }
-                float s = 0.f;
-                for (int k = 0; k < K; k++) {
-                    const float e = pnp_expf(__fsub_rn(row[k], m));
-                    row[k] = e;
-                    s = __fadd_rn(s, e);
-                }
-                for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
-                for (int k = K; k < Kp; k++) row[k] = 0.f;
             }
             __syncthreads();
             for (int item = tid; item < np * K4; item += 256) {

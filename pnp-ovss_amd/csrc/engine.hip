@@ -99,8 +99,9 @@ struct pnp_engine {
         int64_t max_total_pix = 0;
         int B = 0, Cmax = 0, Kmax = 0, maxHW = 0;
         int64_t total_pix = 0;
-        std::vector<PostDesc> desc;
+        std::vector<PostDesc> desc, desc_pair;
         PostDesc* d_desc = nullptr;
+        PostDesc* d_desc_pair = nullptr;      // same batch with two channel groups per row (1-drop | N-drop)
         int32_t *d_img_cls_off = nullptr, *d_cls_off = nullptr, *d_tok_idx = nullptr, *d_cls_div = nullptr, *d_lut = nullptr;
         int lut_stride = 0;
         size_t* d_label_off = nullptr;
@@ -849,6 +850,7 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     p.chunk = crf_chunk > 0 ? crf_chunk : max_batch;
     const size_t TP = (size_t)max_total_pixels, K = max_channels, B = max_batch;
     KCHK(e, dalloc(e, &p.d_desc, B));
+    KCHK(e, dalloc(e, &p.d_desc_pair, B));
     KCHK(e, dalloc(e, &p.d_img_cls_off, B + 1));
     p.cls_cap = (int)(B * K + 1);
     p.tok_cap = (int)(B * e->c.max_text_len + 1);
@@ -870,8 +872,8 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     // CRF
     const size_t Kp = (K + 3) / 4 * 4;
     p.maxKp = (int)Kp;
-    KCHK(e, dalloc(e, &p.unary, TP * Kp));
-    KCHK(e, dalloc(e, &p.Q, TP * Kp));
+    KCHK(e, dalloc(e, &p.unary, TP * Kp * 2));       // x2: the paired 1-drop | N-drop run keeps two channel groups per row
+    KCHK(e, dalloc(e, &p.Q, TP * Kp * 2));
     KCHK(e, dalloc(e, &p.norm[0], TP));
     KCHK(e, dalloc(e, &p.norm[1], TP));
     for (int t = 0; t < 2; t++) {
@@ -910,10 +912,10 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     p.sort_tmp = st;
     // lattice value buffers: the images of one chunk, bilateral upper bound (6 entries per pixel) x K
     const size_t chunk_pix = (size_t)std::min<int64_t>((int64_t)p.chunk * max_pixels_per_image, max_total_pixels);
-    p.val_cap = std::max(chunk_pix * 6 * Kp, cap6);
+    p.val_cap = std::max(chunk_pix * 6 * Kp * 2, cap6);
     KCHK(e, dalloc(e, &p.va, p.val_cap));
     KCHK(e, dalloc(e, &p.vb, p.val_cap));
-    p.valg_cap = chunk_pix * 3 * Kp;
+    p.valg_cap = chunk_pix * 3 * Kp * 2;
     KCHK(e, dalloc(e, &p.vga, p.valg_cap));
     KCHK(e, dalloc(e, &p.vgb, p.valg_cap));
     p.reserved = true;
@@ -947,6 +949,8 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
         d.pix0 = (int)pix;
         d.off = off;
         d.Kp = (d.K + 3) / 4 * 4;
+        d.G = 1;
+        d.Kg = d.Kp;
         d.qoff = qoff;
         label_off[i] = (size_t)pix;
         off += (size_t)d.K * d.H * d.W;
@@ -990,7 +994,8 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
                 p.desc[i].voff[t] = v[t];
                 v[t] += (size_t)p.desc[i].H * p.desc[i].W * (t == 0 ? 3 : 6) * p.desc[i].Kp;
             }
-        if (v[1] > p.val_cap || v[0] > p.valg_cap) return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", v[1], p.val_cap);
+        if (2 * v[1] > p.val_cap || 2 * v[0] > p.valg_cap)       // x2: room for the paired (two-group) run
+            return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", 2 * v[1], p.val_cap);
     }
     p.B = B;
     p.total_pix = pix;
@@ -998,6 +1003,15 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
     p.d_rgb = b->d_rgb;
     p.d_gt = b->d_gt;
     HIPCHK(e, hipMemcpyAsync(p.d_desc, p.desc.data(), sizeof(PostDesc) * B, hipMemcpyHostToDevice, s));
+    p.desc_pair = p.desc;
+    for (PostDesc& d : p.desc_pair) {          // rows of two groups: every row-strided offset doubles
+        d.G = 2;
+        d.Kp = 2 * d.Kg;
+        d.qoff *= 2;
+        d.voff[0] *= 2;
+        d.voff[1] *= 2;
+    }
+    HIPCHK(e, hipMemcpyAsync(p.d_desc_pair, p.desc_pair.data(), sizeof(PostDesc) * B, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(p.d_img_cls_off, b->img_cls_off, 4 * (B + 1), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(p.d_cls_off, b->cls_off, 4 * (ncls + 1), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(p.d_cls_div, b->cls_div, 4 * std::max(ncls, 1), hipMemcpyHostToDevice, s));
@@ -1075,6 +1089,24 @@ extern "C" int pnp_blur_minmax(pnp_engine* e, void* stream) {
     return PNP_OK;
 }
 
+// mean-field iterations over the unary rows already in p.unary; desc = single- or two-group descriptors
+static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s) {
+    auto& p = e->post;
+    for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
+        const int n = std::min(p.chunk, p.B - c0);
+        KCHK(e, crf_update(p.lat[0], p.lat[1], desc, c0, n, p.vga, p.va, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 0,
+                           p.maxHW, kp_max, s));
+        for (int it = 0; it < iters; it++) {
+            const float *rg = nullptr, *rb = nullptr;
+            KCHK(e, crf_filter(p.lat[0], desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, kp_max, s));
+            KCHK(e, crf_filter(p.lat[1], desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, kp_max, s));
+            KCHK(e, crf_update(p.lat[0], p.lat[1], desc, c0, n, rg, rb, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 1,
+                               p.maxHW, kp_max, s));
+        }
+    }
+    return PNP_OK;
+}
+
 extern "C" int pnp_densecrf(pnp_engine* e, int32_t iters, float pos_w, float pos_xy, float bi_w, float bi_xy, float bi_rgb,
                             void* stream) {
     POST_READY(e);
@@ -1084,20 +1116,8 @@ extern "C" int pnp_densecrf(pnp_engine* e, int32_t iters, float pos_w, float pos
         return fail(e, PNP_ERR_ARG, "lattices are built for sxy=3 / sxy=50, srgb=5 (PnP.py:1036-1041)");
     hipStream_t s = (hipStream_t)stream;
     const float* maps = p.maps_in_2 ? p.maps2 : p.maps;
-    KCHK(e, unary_from_maps(maps, p.d_desc, p.unary, p.B, p.maxHW, p.maxKp, s));
-    for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
-        const int n = std::min(p.chunk, p.B - c0);
-        KCHK(e, crf_update(p.lat[0], p.lat[1], p.d_desc, c0, n, p.vga, p.va, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 0,
-                           p.maxHW, p.Kpmax, s));
-        for (int it = 0; it < iters; it++) {
-            const float *rg = nullptr, *rb = nullptr;
-            KCHK(e, crf_filter(p.lat[0], p.d_desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, p.Kpmax, s));
-            KCHK(e, crf_filter(p.lat[1], p.d_desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, p.Kpmax, s));
-            KCHK(e, crf_update(p.lat[0], p.lat[1], p.d_desc, c0, n, rg, rb, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 1,
-                               p.maxHW, p.Kpmax, s));
-        }
-    }
-    return PNP_OK;
+    KCHK(e, unary_from_maps(maps, p.d_desc, p.unary, p.B, p.maxHW, p.maxKp, 0, s));
+    return crf_iterate(e, p.d_desc, p.Kpmax, iters, pos_w, bi_w, s);
 }
 
 extern "C" int pnp_remap_hist(pnp_engine* e, int32_t from_crf, uint8_t* d_labels, unsigned long long* d_hist, int32_t n_class,
@@ -1107,7 +1127,7 @@ extern "C" int pnp_remap_hist(pnp_engine* e, int32_t from_crf, uint8_t* d_labels
     if (!d_labels) return fail(e, PNP_ERR_ARG, "d_labels is null");
     hipStream_t s = (hipStream_t)stream;
     const float* src = from_crf ? p.Q : (p.maps_in_2 ? p.maps2 : p.maps);
-    KCHK(e, argmax_remap(src, p.d_desc, p.d_lut, p.lut_stride, d_labels, p.d_label_off, from_crf ? 1 : 0, p.B, p.maxHW, s));
+    KCHK(e, argmax_remap(src, p.d_desc, p.d_lut, p.lut_stride, d_labels, p.d_label_off, from_crf ? 1 : 0, 0, p.B, p.maxHW, s));
     if (d_hist && p.d_gt) KCHK(e, confusion_hist(d_labels, p.d_gt, p.d_desc, p.d_label_off, d_hist, n_class, p.B, p.maxHW, s));
     return PNP_OK;
 }
@@ -1127,6 +1147,38 @@ extern "C" int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T,
         if (r) return r;
     }
     return pnp_remap_hist(e, (mode & 2) ? 1 : 0, d_labels, d_hist, n_class, stream);
+}
+
+// 1-drop and N-drop "blur+crf" post-processing of one batch in ONE mean-field run (PnP.py:348-403 and 424-481 run the
+// same DenseCRF twice per image on the same RGB image): the two problems become two channel groups of every row, so the
+// lattice index walks -- contributor lists, neighbour ids, simplex offsets -- are shared.  Per-channel arithmetic is
+// untouched: labels and histograms equal two pnp_postprocess calls bit for bit.
+extern "C" int pnp_postprocess_pair(pnp_engine* e, const float* d_gradcam_1drop, const float* d_gradcam_ndrop, int32_t T,
+                                    float threshold, uint8_t* d_labels_1drop, unsigned long long* d_hist_1drop,
+                                    uint8_t* d_labels_ndrop, unsigned long long* d_hist_ndrop, int32_t n_class, void* stream) {
+    POST_READY(e);
+    auto& p = e->post;
+    if (!p.has_crf) return fail(e, PNP_ERR_STATE, "batch was prepared without CRF lattices");
+    if (!d_labels_1drop || !d_labels_ndrop) return fail(e, PNP_ERR_ARG, "label outputs are null");
+    hipStream_t s = (hipStream_t)stream;
+    for (int grp = 0; grp < 2; grp++) {
+        int r = pnp_merge_tokens(e, grp == 0 ? d_gradcam_1drop : d_gradcam_ndrop, T, stream);
+        if (r) return r;
+        r = pnp_threshold_upsample(e, threshold, grp == 0 ? 1 : 0, stream);      // Scale_0_1 in the 1-drop branch only
+        if (r) return r;
+        r = pnp_blur_minmax(e, stream);
+        if (r) return r;
+        KCHK(e, unary_from_maps(p.maps2, p.d_desc_pair, p.unary, p.B, p.maxHW, p.maxKp, grp, s));
+    }
+    int r = crf_iterate(e, p.d_desc_pair, 2 * p.Kpmax, 10, 7.0f, 10.0f, s);
+    if (r) return r;
+    for (int grp = 0; grp < 2; grp++) {
+        uint8_t* lab = grp == 0 ? d_labels_1drop : d_labels_ndrop;
+        unsigned long long* hist = grp == 0 ? d_hist_1drop : d_hist_ndrop;
+        KCHK(e, argmax_remap(p.Q, p.d_desc_pair, p.d_lut, p.lut_stride, lab, p.d_label_off, 1, grp, p.B, p.maxHW, s));
+        if (hist && p.d_gt) KCHK(e, confusion_hist(lab, p.d_gt, p.d_desc, p.d_label_off, hist, n_class, p.B, p.maxHW, s));
+    }
+    return PNP_OK;
 }
 
 // =========================================================================================== introspection

@@ -14,7 +14,9 @@ namespace pnp {
 // lattice value block (t = 0 Gaussian, 1 bilateral).
 struct PostDesc {
     int H, W, K, C, has_bg, pix0;
-    int Kp;            // K rounded up to a multiple of 4 (row stride of the CRF arrays)
+    int Kp;            // row stride of the CRF arrays in floats: G groups of Kg
+    int G, Kg;         // channel groups per row (1; 2 = the 1-drop and N-drop problems of one batch side by side, which
+                       // share every lattice index walk) and floats per group (K rounded up to a multiple of 4)
     size_t off;        // K*H*W blocks of the (K,H,W) map buffers
     size_t qoff;       // Kp*H*W blocks of the pixel-major CRF arrays (unary, Q)
     size_t voff[2];
@@ -77,9 +79,9 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
               int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s);
 int preprocess_images(const uint8_t* rgb, const void* desc, int B, int S, int max_H, const int32_t* coef, uint8_t* tmp,
                       const float* mean3, const float* std3, float* out, hipStream_t s);
-int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, hipStream_t s);
+int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, int group, hipStream_t s);
 int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int lut_stride, uint8_t* labels,
-                 const size_t* label_off, int pixel_major, int B, int maxHW, hipStream_t s);
+                 const size_t* label_off, int pixel_major, int group, int B, int maxHW, hipStream_t s);
 int confusion_hist(const uint8_t* labels, const float* gt, const PostDesc* desc, const size_t* label_off,
                    unsigned long long* hist, int n_class, int B, int maxHW, hipStream_t s);
 

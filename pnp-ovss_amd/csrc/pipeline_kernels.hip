@@ -489,13 +489,13 @@ int preprocess_images(const uint8_t* rgb, const void* desc, int B, int S, int ma
 // softmax over channels + unary = -log(clip(p, 1e-5, 1)), written pixel-major [n][K]
 // (densecrf's value layout).  include/pnp_math.h defines exp/log bit-exactly for host and device.
 __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc,
-                                                    float* __restrict__ unary) {
+                                                    float* __restrict__ unary, int group) {
     // tile of 256 pixels: channel-major reads (coalesced along pixels), results parked in LDS [pixel][Kp + 1], then
     // written as whole 16-byte chunks of the pixel-major rows (the per-thread row writes were 4 bytes at a 96-byte stride)
     extern __shared__ __attribute__((aligned(16))) float utile[];
     const int b = blockIdx.y;
     const PostDesc d = desc[b];
-    const int n = d.H * d.W, K = d.K, Kp = d.Kp, K4 = Kp >> 2, ldt = Kp + 1;
+    const int n = d.H * d.W, K = d.K, Kp = d.Kg, K4 = Kp >> 2, ldt = Kp + 1, R4 = d.Kp >> 2, g4 = group * K4;   // row = G groups of Kg
     const float* m = maps + d.off;
     f32x4* u4 = reinterpret_cast<f32x4*>(unary + d.qoff);
     const int tid = threadIdx.x;
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ ma
         for (int item = tid; item < np * K4; item += 256) {
             const int pl = item / K4, c = item - pl * K4;
             const float* r = utile + pl * ldt + 4 * c;
-            u4[(size_t)(p0 + pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
+            u4[(size_t)(p0 + pl) * R4 + g4 + c] = f32x4{r[0], r[1], r[2], r[3]};
         }
         __syncthreads();
     }
@@ -533,17 +533,17 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ ma
 // np.argmax semantics: first maximum, NaN counts as maximum.
 __global__ void argmax_kernel(const float* __restrict__ q, const PostDesc* __restrict__ desc, const int32_t* __restrict__ lut,
                               int lut_stride, uint8_t* __restrict__ labels, const size_t* __restrict__ label_off,
-                              int pixel_major) {
+                              int pixel_major, int group) {
     const int b = blockIdx.y;
     const PostDesc d = desc[b];
     const int n = d.H * d.W, K = d.K, Kp = d.Kp;
     const float* p = q + (pixel_major ? d.qoff : d.off);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int best = 0;
-        float bv = pixel_major ? p[(size_t)i * Kp] : p[i];
-        if (pixel_major) {                          // rows are Kp = 4 * ceil(K / 4) floats, 16-byte aligned: vector loads
-            const f32x4* row = reinterpret_cast<const f32x4*>(p + (size_t)i * Kp);
-            for (int c = 0; c < Kp / 4; c++) {
+        float bv = pixel_major ? p[(size_t)i * Kp + group * d.Kg] : p[i];
+        if (pixel_major) {                          // rows are G groups of Kg = 4 * ceil(K / 4) floats, 16-byte aligned
+            const f32x4* row = reinterpret_cast<const f32x4*>(p + (size_t)i * Kp + group * d.Kg);
+            for (int c = 0; c < d.Kg / 4; c++) {
                 const f32x4 v4 = row[c];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -666,7 +666,7 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
     return ok();
 }
 
-int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, hipStream_t s) {
+int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, int group, hipStream_t s) {
     const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
     const size_t smem = (size_t)256 * (max_kp + 1) * sizeof(float);
     static bool attr_set = false;
@@ -676,14 +676,14 @@ int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B
             return PNP_ERR_HIP;
         attr_set = true;
     }
-    hipLaunchKernelGGL(unary_kernel, dim3(nb, B), dim3(256), smem, s, maps, desc, unary);
+    hipLaunchKernelGGL(unary_kernel, dim3(nb, B), dim3(256), smem, s, maps, desc, unary, group);
     return ok();
 }
 
 int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int lut_stride, uint8_t* labels,
-                 const size_t* label_off, int pixel_major, int B, int maxHW, hipStream_t s) {
+                 const size_t* label_off, int pixel_major, int group, int B, int maxHW, hipStream_t s) {
     const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
-    hipLaunchKernelGGL(argmax_kernel, dim3(nb, B), dim3(256), 0, s, q, desc, lut, lut_stride, labels, label_off, pixel_major);
+    hipLaunchKernelGGL(argmax_kernel, dim3(nb, B), dim3(256), 0, s, q, desc, lut, lut_stride, labels, label_off, pixel_major, group);
     return ok();
 }
 

@@ -69,6 +69,7 @@ def load_library():
         "pnp_densecrf": (i32, [vp, i32, f32, f32, f32, f32, f32, vp]),
         "pnp_remap_hist": (i32, [vp, i32, vp, vp, i32, vp]),
         "pnp_postprocess": (i32, [vp, vp, i32, f32, i32, i32, vp, vp, i32, vp]),
+        "pnp_postprocess_pair": (i32, [vp, vp, vp, i32, f32, vp, vp, vp, vp, i32, vp]),
         "pnp_get_buffer": (i32, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "pnp_profile_enable": (i32, [vp, i32]),
         "pnp_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -94,7 +95,7 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_finalize_weights", "pnp_vit_forward", "pnp_text_forward_xattn", "pnp_xattn_grad",
             "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
-            "pnp_remap_hist", "pnp_postprocess", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images"]
+            "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images"]
 
 
 class _DevView:
@@ -390,6 +391,18 @@ class Engine:
                                            1 if scale01 else 0, m, _ptr(labels), _ptr(hist), n_class, _stream()),
                   "pnp_postprocess")
         return labels
+
+    def postprocess_pair(self, gradcam_1drop, gradcam_ndrop, threshold, n_class=0, hist_1drop=None, hist_ndrop=None):
+        """Both "blur+crf" branches of a batch (1-drop with Scale_0_1, N-drop without) in one DenseCRF run;
+        returns (labels_1drop, labels_ndrop), identical to two postprocess() calls."""
+        total = sum(h * w for h, w in self._post_sizes)
+        l1 = torch.empty(total, device=self.device, dtype=torch.uint8)
+        ln = torch.empty(total, device=self.device, dtype=torch.uint8)
+        assert gradcam_1drop.shape == gradcam_ndrop.shape
+        self._chk(self.lib.pnp_postprocess_pair(self.h, _ptr(gradcam_1drop), _ptr(gradcam_ndrop), gradcam_1drop.shape[1],
+                                                float(threshold), _ptr(l1), _ptr(hist_1drop), _ptr(ln), _ptr(hist_ndrop),
+                                                n_class, _stream()), "pnp_postprocess_pair")
+        return l1, ln
 
     def split_labels(self, labels):
         out, o = [], 0

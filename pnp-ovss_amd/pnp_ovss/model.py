@@ -245,6 +245,10 @@ class Segmenter:
             gt = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in label_trues])).to(dev)
         eng.post_prepare(sizes, plans, luts, bgs, rgb=rgb, gt=gt, want_crf=bool(self.mode and "crf" in self.mode))
         out1 = outn = None
+        if run_1drop and agg is not None and self.mode == "blur+crf":
+            # both branches share the image lattices: one DenseCRF run over two channel groups (same results)
+            l1, ln = eng.postprocess_pair(g0, agg, self.threshold, self.n_class, self.hist_1drop, self.hist_ndrop)
+            return eng.split_labels(l1), eng.split_labels(ln)
         if run_1drop or agg is None:
             out1 = eng.split_labels(eng.postprocess(g0, self.threshold, True, self.mode, self.n_class, self.hist_1drop))
         if agg is not None:

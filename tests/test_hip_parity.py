@@ -682,3 +682,34 @@ def test_postprocess_many_channels_bit_exact_vs_oracle(n_sel, n_class, data_type
     _, ref_hist = OP.scores(gts, ref_labels, n_class)
     np.testing.assert_array_equal(hist.cpu().numpy().reshape(n_class, n_class), ref_hist.astype(np.int64))
     e.close()
+
+
+@pytest.mark.parametrize("data_type", ["voc", "psc"])
+def test_postprocess_pair_equals_two_single_runs(data_type):
+    """pnp_postprocess_pair (1-drop | N-drop as two channel groups of one DenseCRF run) against two pnp_postprocess calls on
+    the same prepared batch: label maps and confusion matrices identical, for ragged sizes / class counts."""
+    cfg, maps, pieces, classes, sizes, rgb, best, gts = _post_case(seed=3)
+    rng = np.random.default_rng(17)
+    maps_n = maps + (rng.random(maps.shape, dtype=np.float32) ** 3) * (maps > 0)          # "agg": another map set, same masks
+    has_bg = [OP.has_background(data_type, len(b)) for b in best]
+    K = [len(b) + int(h) for b, h in zip(best, has_bg)]
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    e = Engine(cfg, max_batch=4, max_text_len=32, stash_layer=7, bf16=False)
+    e.post_reserve(4, 4 * 128 * 128, 128 * 128, 8, 0)
+    e.post_prepare(sizes, _plans(pieces, [len(b) for b in best]), [_lut(b, h, k) for b, h, k in zip(best, has_bg, K)], has_bg,
+                   rgb=_dev(np.concatenate([r.reshape(-1) for r in rgb])), gt=_dev(np.concatenate([g.reshape(-1) for g in gts])),
+                   want_crf=True)
+    d1, dn = _dev(maps), _dev(maps_n)
+    h1 = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    hn = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    ref1 = e.postprocess(d1, 0.15, True, "blur+crf", 21, h1).clone()
+    refn = e.postprocess(dn, 0.15, False, "blur+crf", 21, hn).clone()
+    p1 = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    pn = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    got1, gotn = e.postprocess_pair(d1, dn, 0.15, 21, p1, pn)
+    torch.cuda.synchronize()
+    assert torch.equal(got1, ref1) and torch.equal(gotn, refn)
+    assert torch.equal(p1, h1) and torch.equal(pn, hn)
+    assert int(h1.sum()) == sum(h * w for h, w in sizes) and not torch.equal(ref1, refn)
+    e.close()
