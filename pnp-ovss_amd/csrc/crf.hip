@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
         const int lo_g = pairwise ? Lg.idbase[b] : 0, lo_b = pairwise ? Lb.idbase[b] : 0;
         const f32x4* G4 = reinterpret_cast<const f32x4*>(vg + im.voff[0]);
         const f32x4* B4 = reinterpret_cast<const f32x4*>(vb + im.voff[1]);
-        for (int p0 = slot * CRF_TP; p0 < n; p0 += bpx * CRF_TP) {
-            const int np = (n - p0) < CRF_TP ? (n - p0) : CRF_TP;
+        const int TP = CRF_TP / im.G;                                   // pixels per tile: one softmax thread per (pixel, group)
+        for (int p0 = slot * TP; p0 < n; p0 += bpx * TP) {
+            const int np = (n - p0) < TP ? (n - p0) : TP;
             for (int item = tid; item < np * K4; item += 256) {
                 const int pl = item / K4, c = item - pl * K4;
                 const int pix = p0 + pl;
@@ -458,23 +459,22 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
                 for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
             }
             __syncthreads();
-            if (tid < np) {
-                for (int grp = 0; grp < im.G; grp++) {              // one softmax per channel group
-                    float* row = tile + tid * ldt + grp * im.Kg;
-                    float m = row[0];
-                    for (int k = 1; k < K; k++) {
-                        const float v = row[k];
-                        if (v > m || v != v) m = v;
-                    }
-                    float s = 0.f;
-                    for (int k = 0; k < K; k++) {
-                        const float e = pnp_expf(__fsub_rn(row[k], m));
-                        row[k] = e;
-                        s = __fadd_rn(s, e);
-                    }
-                    for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
-                    for (int k = K; k < im.Kg; k++) row[k] = 0.f;
+            if (tid < np * im.G) {                                      // one softmax per (pixel, channel group)
+                const int grp = tid / np, px = tid - grp * np;
+                float* row = tile + px * ldt + grp * im.Kg;
+                float m = row[0];
+                for (int k = 1; k < K; k++) {
+                    const float v = row[k];
+                    if (v > m || v != v) m = v;
                 }
+                float s = 0.f;
+                for (int k = 0; k < K; k++) {
+                    const float e = pnp_expf(__fsub_rn(row[k], m));
+                    row[k] = e;
+                    s = __fadd_rn(s, e);
+                }
+                for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
+                for (int k = K; k < im.Kg; k++) row[k] = 0.f;
             }
             __syncthreads();
             for (int item = tid; item < np * K4; item += 256) {
@@ -667,8 +667,8 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
 // Q <- softmax(-U - pairwise terms) (pairwise != 0) or softmax(-U) (pairwise == 0)
 int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
                const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
-               float w_b, int pairwise, int max_pixels, int max_kp, hipStream_t s) {
-    const size_t smem = (size_t)CRF_TP * (max_kp + 1) * sizeof(float);
+               float w_b, int pairwise, int max_pixels, int max_kp, int groups, hipStream_t s) {
+    const size_t smem = (size_t)(CRF_TP / (groups > 0 ? groups : 1)) * (max_kp + 1) * sizeof(float);
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(crf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)

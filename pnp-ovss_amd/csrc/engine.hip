@@ -1092,16 +1092,17 @@ extern "C" int pnp_blur_minmax(pnp_engine* e, void* stream) {
 // mean-field iterations over the unary rows already in p.unary; desc = single- or two-group descriptors
 static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s) {
     auto& p = e->post;
+    const int groups = desc == p.d_desc_pair ? 2 : 1;
     for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
         const int n = std::min(p.chunk, p.B - c0);
         KCHK(e, crf_update(p.lat[0], p.lat[1], desc, c0, n, p.vga, p.va, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 0,
-                           p.maxHW, kp_max, s));
+                           p.maxHW, kp_max, groups, s));
         for (int it = 0; it < iters; it++) {
             const float *rg = nullptr, *rb = nullptr;
             KCHK(e, crf_filter(p.lat[0], desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, kp_max, s));
             KCHK(e, crf_filter(p.lat[1], desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, kp_max, s));
             KCHK(e, crf_update(p.lat[0], p.lat[1], desc, c0, n, rg, rb, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 1,
-                               p.maxHW, kp_max, s));
+                               p.maxHW, kp_max, groups, s));
         }
     }
     return PNP_OK;

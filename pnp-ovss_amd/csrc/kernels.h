@@ -97,6 +97,6 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
                float* va, float* vb, const float** result, int max_kp, hipStream_t s);
 int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
                const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
-               float w_b, int pairwise, int max_pixels, int max_kp, hipStream_t s);
+               float w_b, int pairwise, int max_pixels, int max_kp, int groups, hipStream_t s);
 
 }  // namespace pnp
