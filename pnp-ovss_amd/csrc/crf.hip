@@ -301,6 +301,26 @@ __global__ void crf_norm_kernel(const CrfLattice L, const PostDesc* __restrict__
 // smallest that covers the widest row of the batch, so the contributor list of a point is walked once
 // (with LPP = 8 a 36-float row walked it twice: +43 % on the whole mean-field pass).
 //
+// Image schedule of an XCD: whole images img0 + xcd, + 8, ... while a full round of 8 remains; the last nimg % 8 images
+// are cut into 8 equal slices, one per XCD (with 35 images three XCDs would otherwise sweep a fifth image while five
+// idle: 12.5 % of every iteration kernel).
+__device__ __forceinline__ bool xcd_work(int i, int xcd, int img0, int nimg, int& b, int& part, int& parts) {
+    const int full = nimg >> 3;
+    if (i < full) {
+        b = img0 + i * 8 + xcd;
+        part = 0;
+        parts = 1;
+        return true;
+    }
+    if (i - full < (nimg & 7)) {
+        b = img0 + full * 8 + (i - full);
+        part = xcd;
+        parts = 8;
+        return true;
+    }
+    return false;
+}
+
 // splat: val[id] = sum over the lattice point's contributors (ascending pixel) of bary * (Q * norm)
 template <int D1, int LPP>
 __global__ __launch_bounds__(256) void crf_splat4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
@@ -309,13 +329,15 @@ __global__ __launch_bounds__(256) void crf_splat4_kernel(const CrfLattice L, con
     constexpr int PPB = 256 / LPP;                       // lattice points per workgroup pass
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const int c0 = threadIdx.x & (LPP - 1), pl = threadIdx.x / LPP;
-    for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
+    int b, part, parts;
+    for (int wi = 0; xcd_work(wi, xcd, img0, nimg, b, part, parts); wi++) {
         const PostDesc im = imgs[b];
         const int K4 = im.Kp >> 2;
         const int lo = L.idbase[b], hi = L.idbase[b + 1];
         const f32x4* Q4 = reinterpret_cast<const f32x4*>(Q + im.qoff);
         f32x4* V4 = reinterpret_cast<f32x4*>(val + im.voff[L.which]);
-        for (int idl = slot * PPB + pl; idl < hi - lo; idl += bpx * PPB) {
+        const int r0 = (int)((long)(hi - lo) * part / parts), r1 = (int)((long)(hi - lo) * (part + 1) / parts);
+        for (int idl = r0 + slot * PPB + pl; idl < r1; idl += bpx * PPB) {
             const int e0 = L.seg_lo[lo + idl], e1 = L.seg_hi[lo + idl];
             for (int c = c0; c < K4; c += LPP) {
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -360,14 +382,16 @@ __global__ __launch_bounds__(256) void crf_blur4_kernel(const CrfLattice L, cons
     const int* n1 = L.n1 + (size_t)axis * L.cap;
     const int* n2 = L.n2 + (size_t)axis * L.cap;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
+    int b, part, parts;
+    for (int wi = 0; xcd_work(wi, xcd, img0, nimg, b, part, parts); wi++) {
         const PostDesc im = imgs[b];
         const int K4 = im.Kp >> 2;
         const int lo = L.idbase[b], hi = L.idbase[b + 1];
         const f32x4* S4 = reinterpret_cast<const f32x4*>(src + im.voff[L.which]);
         f32x4* D4 = reinterpret_cast<f32x4*>(dst + im.voff[L.which]);
-        const int nitem = (hi - lo) * K4, stride = bpx * 256;
-        for (int it0 = slot * 256 + threadIdx.x; it0 < nitem; it0 += 2 * stride) {
+        const int first = (int)((long)(hi - lo) * part / parts) * K4;
+        const int nitem = (int)((long)(hi - lo) * (part + 1) / parts) * K4, stride = bpx * 256;
+        for (int it0 = first + slot * 256 + threadIdx.x; it0 < nitem; it0 += 2 * stride) {
             const int it1 = it0 + stride;
             const bool two = it1 < nitem;
             const int p0 = it0 / K4, p1 = two ? it1 / K4 : p0;
@@ -407,9 +431,11 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
     // its XCD has just blurred
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const int tid = threadIdx.x;
-    for (int b = img0 + xcd; b < img0 + nimg; b += 8) {
+    int b, part, parts;
+    for (int wi = 0; xcd_work(wi, xcd, img0, nimg, b, part, parts); wi++) {
         const PostDesc im = imgs[b];
-        const int n = im.H * im.W;
+        const int npix = im.H * im.W;
+        const int pfirst = (int)((long)npix * part / parts), n = (int)((long)npix * (part + 1) / parts);
         const int K = im.K, Kp = im.Kp, K4 = Kp >> 2, ldt = Kp + 1;
         const f32x4* U4 = reinterpret_cast<const f32x4*>(unary + im.qoff);
         f32x4* Q4 = reinterpret_cast<f32x4*>(Q + im.qoff);
@@ -417,7 +443,7 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
         const f32x4* G4 = reinterpret_cast<const f32x4*>(vg + im.voff[0]);
         const f32x4* B4 = reinterpret_cast<const f32x4*>(vb + im.voff[1]);
         const int TP = CRF_TP / im.G;                                   // pixels per tile: one softmax thread per (pixel, group)
-        for (int p0 = slot * TP; p0 < n; p0 += bpx * TP) {
+        for (int p0 = pfirst + slot * TP; p0 < n; p0 += bpx * TP) {
             const int np = (n - p0) < TP ? (n - p0) : TP;
             for (int item = tid; item < np * K4; item += 256) {
                 const int pl = item / K4, c = item - pl * K4;
