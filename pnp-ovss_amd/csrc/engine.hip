@@ -95,6 +95,7 @@ struct pnp_engine {
     // ---- post-process state
     struct Post {
         bool reserved = false, prepared = false, has_crf = false;
+        int groups_cap = 1;                   // 2: the CRF arrays were sized for the paired (two-group) run
         int maxB = 0, maxK = 0, max_pix_img = 0, chunk = 0;
         int64_t max_total_pix = 0;
         int B = 0, Cmax = 0, Kmax = 0, maxHW = 0;
@@ -872,8 +873,16 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     // CRF
     const size_t Kp = (K + 3) / 4 * 4;
     p.maxKp = (int)Kp;
-    KCHK(e, dalloc(e, &p.unary, TP * Kp * 2));       // x2: the paired 1-drop | N-drop run keeps two channel groups per row
-    KCHK(e, dalloc(e, &p.Q, TP * Kp * 2));
+    // the paired 1-drop | N-drop run keeps two channel groups per row: size the CRF arrays for it unless that would
+    // take more than 96 GB (many classes x large images); pnp_postprocess_pair then runs the two branches one after the other
+    {
+        const size_t chunk_pix0 = (size_t)std::min<int64_t>((int64_t)(crf_chunk > 0 ? crf_chunk : B) * max_pixels_per_image, max_total_pixels);
+        const size_t single = (2 * TP * Kp + 2 * chunk_pix0 * 6 * Kp + 2 * chunk_pix0 * 3 * Kp) * sizeof(float);
+        p.groups_cap = 2 * single <= ((size_t)96 << 30) ? 2 : 1;
+    }
+    const size_t G2 = (size_t)p.groups_cap;
+    KCHK(e, dalloc(e, &p.unary, TP * Kp * G2));
+    KCHK(e, dalloc(e, &p.Q, TP * Kp * G2));
     KCHK(e, dalloc(e, &p.norm[0], TP));
     KCHK(e, dalloc(e, &p.norm[1], TP));
     for (int t = 0; t < 2; t++) {
@@ -912,10 +921,10 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     p.sort_tmp = st;
     // lattice value buffers: the images of one chunk, bilateral upper bound (6 entries per pixel) x K
     const size_t chunk_pix = (size_t)std::min<int64_t>((int64_t)p.chunk * max_pixels_per_image, max_total_pixels);
-    p.val_cap = std::max(chunk_pix * 6 * Kp * 2, cap6);
+    p.val_cap = std::max(chunk_pix * 6 * Kp * G2, cap6);
     KCHK(e, dalloc(e, &p.va, p.val_cap));
     KCHK(e, dalloc(e, &p.vb, p.val_cap));
-    p.valg_cap = chunk_pix * 3 * Kp * 2;
+    p.valg_cap = chunk_pix * 3 * Kp * G2;
     KCHK(e, dalloc(e, &p.vga, p.valg_cap));
     KCHK(e, dalloc(e, &p.vgb, p.valg_cap));
     p.reserved = true;
@@ -994,8 +1003,8 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
                 p.desc[i].voff[t] = v[t];
                 v[t] += (size_t)p.desc[i].H * p.desc[i].W * (t == 0 ? 3 : 6) * p.desc[i].Kp;
             }
-        if (2 * v[1] > p.val_cap || 2 * v[0] > p.valg_cap)       // x2: room for the paired (two-group) run
-            return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", 2 * v[1], p.val_cap);
+        if (p.groups_cap * v[1] > p.val_cap || p.groups_cap * v[0] > p.valg_cap)     // incl. room for the paired run
+            return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", p.groups_cap * v[1], p.val_cap);
     }
     p.B = B;
     p.total_pix = pix;
@@ -1161,6 +1170,11 @@ extern "C" int pnp_postprocess_pair(pnp_engine* e, const float* d_gradcam_1drop,
     auto& p = e->post;
     if (!p.has_crf) return fail(e, PNP_ERR_STATE, "batch was prepared without CRF lattices");
     if (!d_labels_1drop || !d_labels_ndrop) return fail(e, PNP_ERR_ARG, "label outputs are null");
+    if (p.groups_cap < 2) {                     // arrays sized for one group only: same results, two passes
+        int r = pnp_postprocess(e, d_gradcam_1drop, T, threshold, 1, 3, d_labels_1drop, d_hist_1drop, n_class, stream);
+        if (r) return r;
+        return pnp_postprocess(e, d_gradcam_ndrop, T, threshold, 0, 3, d_labels_ndrop, d_hist_ndrop, n_class, stream);
+    }
     hipStream_t s = (hipStream_t)stream;
     for (int grp = 0; grp < 2; grp++) {
         int r = pnp_merge_tokens(e, grp == 0 ? d_gradcam_1drop : d_gradcam_ndrop, T, stream);

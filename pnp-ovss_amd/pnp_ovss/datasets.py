@@ -145,7 +145,7 @@ class Ade20kDataset(_Base):
         with open(f"{home}/semantic-segmentation-pytorch-master/data/validation.odgt") as f:
             self.records = [json.loads(l) for l in f if l.strip()]
         self.gpt = host.GptClassTable(f"{home}/GPT4o_classification/ade20k_classification_noboundary.json", "ade20k")
-        self.max_pixels = int(getattr(args, "max_pixels", 0)) or 2100 * 2100
+        self.max_pixels = int(getattr(args, "max_pixels", 0)) or 1024 * 1024     # reserve bound per image; larger images fail loudly
 
     def __len__(self):
         return len(self.records)
