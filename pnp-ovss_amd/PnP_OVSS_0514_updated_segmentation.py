@@ -26,7 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from pnp_ovss import host, synth  # noqa: E402
-from pnp_ovss.datasets import make_dataset  # noqa: E402
+from pnp_ovss.datasets import make_dataset, prefetch  # noqa: E402
 from pnp_ovss.model import Segmenter  # noqa: E402
 
 
@@ -98,7 +98,7 @@ def main(rank, world_size, args):
         Path(f"{args.save_path}/{d}/").mkdir(parents=True, exist_ok=True)
     n_img = 0
     t_loop = time.perf_counter()
-    for bi, batch in enumerate(ds.batches(args.batch_size)):
+    for bi, batch in enumerate(prefetch(ds.batches(args.batch_size), depth=2)):
         if args.max_batches and bi >= args.max_batches:
             break
         best, caps = [], []

@@ -55,6 +55,8 @@ class _Base:
     def batches(self, batch_size):
         """Items whose first element is None get their model tensor from the device-side resize + normalise
         (hip.preprocess_images: Pillow-exact, Dataset.py:434-443 / :1263) over the decoded RGB the CRF uses anyway."""
+        if torch.cuda.is_available():
+            torch.cuda.set_device(self.rank)                     # this generator may run in a prefetch thread (rank = device)
         idx = self._indices(len(self))
         for o in range(0, len(idx), batch_size):
             items = [self[i] for i in idx[o:o + batch_size]]
@@ -162,6 +164,34 @@ class Ade20kDataset(_Base):
 
     def predicted_classes(self, img_id):
         return self.gpt.lookup(img_id, self.nms)
+
+
+def prefetch(iterable, depth=2):
+    """Run `iterable` in a background thread, `depth` items ahead: JPEG decode / ground-truth loading / the device-side
+    resize of batch i+1 overlap the model and CRF work of batch i (the reference's DataLoader runs with
+    num_workers=0 on the main thread, PnP.py:61).  Exceptions of the producer are re-raised in the consumer."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=max(1, depth))
+    end = object()
+
+    def work():
+        try:
+            for item in iterable:
+                q.put(item)
+            q.put(end)
+        except BaseException as exc:       # noqa: BLE001  (handed to the consumer)
+            q.put(exc)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    while True:
+        item = q.get()
+        if item is end:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
 
 
 def make_dataset(args, rank, world_size):
