@@ -62,6 +62,10 @@ int pnp_finalize_weights(pnp_engine* e);
 /* VisionTransformer.forward (B/vit.py:274-290).  d_images: (B,3,S,S) fp32 normalised.
  * d_dropped: optional (B, P*P) uint8, 1 = patch zeroed by the salience drop (PnP.py:597-603). */
 int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream);
+/* key / value Linear(1024 -> 768) of every text layer's cross-attention applied to image_embeds (B/med.py:208-211,
+ * encoder_hidden_states branch), all layers at once.  pnp_vit_forward ends with this call; it is exported on its own
+ * so the projections can be re-run on the engine's current image_embeds (precision probes, tests). */
+int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream);
 /* BertModel.forward(mode="multimodal") + itm_head (B/med.py:854-1024, B/blip_image_text_matching.py:
  * 238-249); stashes the cross-attention probabilities of layers >= stash_layer (B/med.py:280-283).
  * d_ids / d_mask: (B, ld) int64, the first L columns are used (padding="longest"). */
@@ -138,9 +142,11 @@ int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T, float thre
 
 /* Both post-processing branches of a batch -- 1-drop (PnP.py:348-403, with Scale_0_1) and N-drop (PnP.py:424-481) --
  * with "blur+crf" in one DenseCRF run: the two problems share the image's lattices, so they are iterated side by side
- * (two channel groups per row).  Results equal two pnp_postprocess(..., mode 3, ...) calls bit for bit. */
+ * (two channel groups per row).  Results equal two pnp_postprocess(..., mode 3, ...) calls bit for bit.
+ * scale01_mask: bit 0 = Scale_0_1 on the 1-drop maps, bit 1 = on the N-drop maps (PnP.py: 1; the COCO driver
+ * PnP_OVSS_0514_updated_segmentation_coco.py:436,527 scales both: 3). */
 int pnp_postprocess_pair(pnp_engine* e, const float* d_gradcam_1drop, const float* d_gradcam_ndrop, int32_t T, float threshold,
-                         uint8_t* d_labels_1drop, unsigned long long* d_hist_1drop, uint8_t* d_labels_ndrop,
+                         int32_t scale01_mask, uint8_t* d_labels_1drop, unsigned long long* d_hist_1drop, uint8_t* d_labels_ndrop,
                          unsigned long long* d_hist_ndrop, int32_t n_class, void* stream);
 
 /* ---- input side ("next" row: the tensors the reference's datasets hand to the model) -------
@@ -166,11 +172,16 @@ int pnp_preprocess_images(const uint8_t* d_rgb, const pnp_pre_image* d_desc, int
  * "crf_q", "P", "dP", "crf_M" (int32 [2][B+1] lattice id bases), ... */
 int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, size_t* bytes);
 /* Live kernel timing for bench.py's roofline line: while enabled, every launch of the dominant
- * kernel (the 128x128-tile NT GEMM) is bracketed by hipEvents on the launch stream.  pnp_profile_read
+ * kernel family (the dense NT GEMMs with M = B*N rows: gemm_nt_wide_kernel in bf16 mode,
+ * gemm_nt_big_kernel<float> in fp32 mode) is bracketed by hipEvents on the launch stream.  pnp_profile_read
  * synchronises those events and returns launches, summed algorithmic FLOPs (2*M*N*K) and summed
  * kernel milliseconds since the last enable.  Off by default (no events on the hot path). */
 int pnp_profile_enable(pnp_engine* e, int32_t on);
 int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms);
+/* Same for a pipeline stage: 0 = the dense GEMMs (as pnp_profile_read), 1 = the DenseCRF mean-field iterations
+ * (PnP.py:1066-1072: splat / lattice blur / slice + update kernels of one batch, bracketed as a whole); `work` is
+ * FLOPs for stage 0 and algorithmic bytes for stage 1: iterations x (2 x 9 + 2) x K x H x W x 4. */
+int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* launches, double* work, double* ms);
 /* Stand-alone operator entry points used by the parity tests (device pointers, see csrc/). */
 int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,
                 const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, int32_t gelu,

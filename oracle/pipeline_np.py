@@ -13,6 +13,10 @@ Shorthand: PnP.py = /root/reference/PnP_OVSS_0514_updated_segmentation.py
   postprocess              PnP.py:1002-1028
   remap_labels             PnP.py:390-399 / 468-480
   fast_hist, scores        PnP.py:1106-1146
+COCO driver (PnPc.py = /root/reference/PnP_OVSS_0514_updated_segmentation_coco.py):
+  parse_gpt_classes_coco   PnPc.py:858-963  Load_predicted_classes (category id -> position in `cats`)
+  coco rules in segment_batch: 1-drop branch only when drop_iter < 3 (:420), Scale_0_1 on the N-drop branch too
+  (:527), background rule (:446-450, :470-473), remap through cats[..]['id'] (:458-463, :482-489, :549-556, :577-584)
 Pinned against tests/golden/*.npz produced by running the reference's own functions.
 """
 import ctypes
@@ -55,6 +59,44 @@ def parse_gpt_classes(per_img_cls: str, nms):
     idx = [int(cls_list[i].split(":")[0]) for i, p in enumerate(prob_list) if p > 70]
     best = [i - 1 for i in idx]
     names = [nms[i - 1] for i in idx]
+    if not best:
+        best, names = [0], [nms[0]]
+    return best, names, "A picture of " + " ".join(names)
+
+
+def parse_gpt_classes_coco(per_img_cls: str, cats, nms, data_type="coco_object"):
+    """PnPc.py:870-905 (coco_object) / :918-958 (coco_stuff).  `cats` = list of {'id', 'name'} in pycocotools
+    order, nms[j] the blank/dash-stripped name of cats[j] (PnPc.py:1399-1400).  The class number GPT-4o printed is a
+    COCO category id; best_class_idx is its position in `cats`; ids that are no category are skipped."""
+    parts = per_img_cls.replace(']\n\n[', '], [').replace('],\n\n[', '], [').replace('], \n[', '], [ ') \
+        .replace('],\n[', '], [ ').replace(']\n[', '], [ ').strip("][").split("], [")
+    cls_list = parts[0].split(",")
+    if len(parts) == 1 and parts[0] == '':
+        cls_list = ["1: 'person'" for _ in range(len(cls_list))]
+        prob_list = [100 for _ in range(len(cls_list))]
+    elif len(parts) == 1:
+        prob_list = [100 for _ in range(len(cls_list))]
+    else:
+        prob_list = [int(p.split(":")[-1].split("%")[0]) for p in parts[1].split(",")]
+    if data_type == "coco_stuff":
+        prob_list = prob_list[:len(cls_list)]
+    ids = []
+    for i, p in enumerate(prob_list):
+        if p > 70:
+            if data_type == "coco_stuff":
+                try:
+                    ids.append(int(cls_list[i].split(":")[0]))
+                except Exception:          # noqa: BLE001  (PnPc.py:943-946 swallows everything here)
+                    pass
+            else:
+                ids.append(int(cls_list[i].split(":")[0]))
+    best, names = [], []
+    for v in ids:
+        for j, cat in enumerate(cats):
+            if cat["id"] == v:
+                best.append(j)
+                names.append(nms[j])
+                break
     if not best:
         best, names = [0], [nms[0]]
     return best, names, "A picture of " + " ".join(names)
@@ -309,10 +351,6 @@ def densecrf(rgb, maps, want_q=False, **kw):
     return out
 
 
-def np_argmax_nanfirst(x):
-    return np.argmax(x, axis=0)
-
-
 def postprocess(mode, maps, rgb, hw):
     """PnP.py:1002-1028.  mode: 'blur+crf' | 'crf' | 'blur' | None."""
     if mode is None:
@@ -326,18 +364,19 @@ def postprocess(mode, maps, rgb, hw):
 
 # --------------------------------------------------------------------------- a-13 / a-14
 
-def remap_labels(label_map, best_class_idx, has_background):
-    """PnP.py:390-399: descending i, in place, order-dependent collisions kept."""
+def remap_labels(label_map, best_class_idx, has_background, class_ids=None):
+    """PnP.py:390-399: descending i, in place, order-dependent collisions kept.  COCO (PnPc.py:458-463 ...):
+    the target is cats[best_class_idx[i]]['id'] (`class_ids[j]` = id of cats[j]) instead of index + 1."""
     out = label_map.copy()
     for i in range(len(best_class_idx) - 1, -1, -1):
         src = i + 1 if has_background else i
-        out[out == src] = best_class_idx[i] + 1
+        out[out == src] = best_class_idx[i] + 1 if class_ids is None else class_ids[best_class_idx[i]]
     return out
 
 
 def has_background(data_type, n_sel):
-    """PnP.py:373-379."""
-    return data_type == "voc" or n_sel < 3
+    """PnP.py:373-379; PnPc.py:446-450 / :470-473 (coco_object always, coco_stuff like the context datasets)."""
+    return data_type in ("voc", "coco_object") or n_sel < 3
 
 
 def fast_hist(label_true, label_pred, n_class):
@@ -366,13 +405,18 @@ def scores(label_trues, label_preds, n_class):
 
 def segment_batch(W, cfg, imgs, ids500, mask500, pieces_per_img, best_idx_per_img, rgbs, sizes,
                   data_type="voc", drop_iter=4, layer=7, head=9, threshold=0.15, mode="blur+crf",
-                  run_1drop=True, gradcam_fn=None):
-    """save_img_union_attention (PnP.py:290-521) minus file I/O: returns
-    (labels_1drop list|None, labels_ndrop list|None, aux dict)."""
+                  run_1drop=True, gradcam_fn=None, class_ids=None):
+    """save_img_union_attention (PnP.py:290-521; COCO driver PnPc.py:338-642) minus file I/O: returns
+    (labels_1drop list|None, labels_ndrop list|None, aux dict).  data_type coco_object / coco_stuff: the 1-drop
+    branch runs only when drop_iter < 3, the N-drop branch is Scale_0_1'ed too, labels are COCO category ids
+    (`class_ids[j]` = cats[j]['id'])."""
     g0, agg, picks = drop_loop(W, cfg, imgs, ids500, mask500, drop_iter, layer, head, gradcam_fn)
     out1, outn, pre = [], [], {"1": [], "n": []}
     B = imgs.shape[0]
-    for branch, src, scale01, dst in (("1", g0, True, out1), ("n", agg, False, outn)):
+    coco = data_type.startswith("coco")
+    if coco and drop_iter >= 3:
+        run_1drop = False
+    for branch, src, scale01, dst in (("1", g0, True, out1), ("n", agg, coco, outn)):
         if src is None or (branch == "1" and not run_1drop):
             continue
         for b in range(B):
@@ -383,5 +427,5 @@ def segment_batch(W, cfg, imgs, ids500, mask500, pieces_per_img, best_idx_per_im
             maps = threshold_upsample(merged, H, Wd, threshold, scale01, bg)
             pre[branch].append(maps)
             lab = postprocess(mode, maps, rgbs[b], (H, Wd))
-            dst.append(remap_labels(lab, best, bg))
+            dst.append(remap_labels(lab, best, bg, class_ids))
     return (out1 or None), (outn or None), dict(g0=g0, agg=agg, picks=picks, pre=pre)

@@ -54,11 +54,15 @@ def get_args_parser():
     p.add_argument("--layer", default=None, type=str)
     p.add_argument("--cal_token_sim_forall_layerhead", action="store_true")
     p.add_argument("--in_the_wild", action="store_true")
-    p.add_argument("--data_type", default=None, type=str, help="voc, psc, ade20k or synthetic")
+    p.add_argument("--data_type", default=None, type=str, help="voc, psc, ade20k, coco_object, coco_stuff or synthetic")
     p.add_argument("--postprocess", default=None, type=str, help="blur or crf or blur+crf")
     p.add_argument("--threshold", default=None, type=float)
     # additions
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="f32", choices=["bf16", "f32"],
+                   help="f32 (default): the reference's arithmetic -- same patch picks and label maps as the reference's own "
+                        "fp32 run; bf16: 3.8x the throughput, but ~1%% error on image_embeds moves near-tie patch picks, "
+                        "so ~5-10%% of label pixels differ (tests/test_hip_parity.py::test_bf16_vs_f32_divergence_is_bounded)")
+    p.add_argument("--crf_chunk", default=0, type=int, help="images per DenseCRF launch group (0 = the whole batch)")
     p.add_argument("--checkpoint", default=None, help="BLIP ITM-large checkpoint (.pth); default: seeded synthetic weights")
     p.add_argument("--vocab", default=None, help="bert-base-uncased vocab.txt")
     p.add_argument("--synthetic_images", default=70, type=int)
@@ -90,9 +94,11 @@ def main(rank, world_size, args):
         "blip_image_text_matching", "large", device=rank, is_eval=True, img_size=args.img_size,
         max_batch=args.batch_size, stash_layer=args.max_att_block_num - 1, bf16=(args.dtype == "bf16"),
         checkpoint=args.checkpoint, vocab=args.vocab, max_text_len=ds.max_text_len)
-    n_class = len(ds.cats) + 1
+    coco = args.data_type in ("coco_object", "coco_stuff")
+    n_class = host.coco_n_class(args.data_type) if coco else len(ds.cats) + 1        # PnPc.py:597-600 / PnP.py:1115
     seg = Segmenter(model, args.data_type if args.data_type != "synthetic" else "voc", n_class, threshold=args.threshold,
-                    postprocess=args.postprocess, max_pixels_per_image=ds.max_pixels, max_channels=ds.max_channels)
+                    postprocess=args.postprocess, max_pixels_per_image=ds.max_pixels, max_channels=ds.max_channels,
+                    crf_chunk=args.crf_chunk, class_ids=ds.class_ids)
     layer, head = args.max_att_block_num, int(args.prune_att_head)
     for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
         Path(f"{args.save_path}/{d}/").mkdir(parents=True, exist_ok=True)
@@ -113,10 +119,11 @@ def main(rank, world_size, args):
         h1 = seg.hist_1drop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
         hn = seg.hist_ndrop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
         first = batch["img_ids"][0]
-        np.save(f"{args.save_path}/hist_withfiltered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", h1)
+        if l1 is not None:                      # the COCO driver skips the 1-drop branch when drop_iter >= 3 (PnPc.py:420,633)
+            np.save(f"{args.save_path}/hist_withfiltered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", h1)
         if ln is not None:
             np.save(f"{args.save_path}/all_drop_hist_with_filtered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", hn)
-        print(batch["img_ids"][:3], "miou filtered_caption", host.scores_from_hist(h1)["Mean IoU"],
+        print(batch["img_ids"][:3], "miou filtered_caption", host.scores_from_hist(h1)["Mean IoU"] if l1 is not None else None,
               "miou all_drop", host.scores_from_hist(hn)["Mean IoU"] if ln is not None else None, flush=True)
         n_img += len(batch["img_ids"])
         ds.total_hist += hn if ln is not None else h1

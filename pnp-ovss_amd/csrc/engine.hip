@@ -127,6 +127,16 @@ struct pnp_engine {
         int lut_cap = 0, cls_cap = 0, tok_cap = 0, wts_cap = 0;
         bool maps_in_2 = false;   // where the current maps live after blur
     } post;
+
+    // live timing of one pipeline stage (bench.py's hbm roofline record for the DenseCRF mean-field): event pairs
+    // on the launch stream around the stage, algorithmic bytes summed beside them
+    struct StageProfile {
+        bool on = false;
+        std::vector<hipEvent_t> ev0, ev1;
+        int used = 0;
+        long long launches = 0;
+        double work = 0;
+    } crf_prof;
 };
 
 namespace {
@@ -242,6 +252,8 @@ extern "C" void pnp_destroy(pnp_engine* e) {
     (void)hipDeviceSynchronize();
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& b : e->staging) if (b.p) (void)hipFree(b.p);
+    for (hipEvent_t ev : e->crf_prof.ev0) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->crf_prof.ev1) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -639,7 +651,19 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
         }
     }
     KCHK(e, layernorm(bf, e->x, e->vnorm_w, e->vnorm_b, e->c.vit_ln_eps, M, D, e->emb32, e->embT, nullptr, nullptr, s));
-    // cross-attention K / V projections of all text layers in four GEMMs (natural + transposed layouts)
+    return pnp_cross_kv(e, B, stream);
+}
+
+// encoder_hidden_states -> key / value of every text layer's cross-attention (B/med.py:208-211): the reference
+// projects image_embeds once per layer inside BertSelfAttention.forward; here all 12 layers are projected in four
+// GEMMs (natural + transposed layouts) right after the ViT, from the compute-type copy of image_embeds.
+extern "C" int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream) {
+    if (!e) return PNP_ERR_ARG;
+    if (!e->finalized) return fail(e, PNP_ERR_STATE, "weights not finalized");
+    if (B <= 0 || B > e->c.max_batch) return fail(e, PNP_ERR_ARG, "batch %d out of range (max %d)", B, e->c.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int D = e->D, N = e->N, M = B * N, bf = e->bf;
+    const int ldv = e->c.max_batch * e->Npad;
     const int H = e->H, TL = e->TL, SL = e->SL;
     {
         GemmArgs g = G_(e->embT, D, e->ck_w, D, M, TL * H, D);
@@ -1099,7 +1123,36 @@ extern "C" int pnp_blur_minmax(pnp_engine* e, void* stream) {
 }
 
 // mean-field iterations over the unary rows already in p.unary; desc = single- or two-group descriptors
+static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s);
+
 static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s) {
+    auto& pf = e->crf_prof;
+    const bool timed = pf.on && pf.used < 4096;
+    if (timed) {
+        if ((int)pf.ev0.size() <= pf.used) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(e, PNP_ERR_HIP, "hipEventCreate failed");
+            pf.ev0.push_back(a);
+            pf.ev1.push_back(b);
+        }
+        (void)hipEventRecord(pf.ev0[pf.used], s);
+    }
+    const int r = crf_iterate_body(e, desc, kp_max, iters, pos_w, bi_w, s);
+    if (timed) {
+        (void)hipEventRecord(pf.ev1[pf.used], s);
+        pf.used++;
+        pf.launches++;
+        // per mean-field iteration splat + slice of (3 + 6) simplex vertices per pixel and channel, each
+        // a 4-byte read or write, plus Q read and written once: (2 * 9 + 2) * K * H * W * 4 bytes
+        const auto& p = e->post;
+        const int groups = desc == p.d_desc_pair ? 2 : 1;
+        for (int i = 0; i < p.B; i++)
+            pf.work += (double)iters * 20.0 * 4.0 * groups * p.desc[i].K * (double)p.desc[i].H * p.desc[i].W;
+    }
+    return r;
+}
+
+static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s) {
     auto& p = e->post;
     const int groups = desc == p.d_desc_pair ? 2 : 1;
     for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
@@ -1164,22 +1217,22 @@ extern "C" int pnp_postprocess(pnp_engine* e, const float* d_gradcam, int32_t T,
 // lattice index walks -- contributor lists, neighbour ids, simplex offsets -- are shared.  Per-channel arithmetic is
 // untouched: labels and histograms equal two pnp_postprocess calls bit for bit.
 extern "C" int pnp_postprocess_pair(pnp_engine* e, const float* d_gradcam_1drop, const float* d_gradcam_ndrop, int32_t T,
-                                    float threshold, uint8_t* d_labels_1drop, unsigned long long* d_hist_1drop,
+                                    float threshold, int32_t scale01_mask, uint8_t* d_labels_1drop, unsigned long long* d_hist_1drop,
                                     uint8_t* d_labels_ndrop, unsigned long long* d_hist_ndrop, int32_t n_class, void* stream) {
     POST_READY(e);
     auto& p = e->post;
     if (!p.has_crf) return fail(e, PNP_ERR_STATE, "batch was prepared without CRF lattices");
     if (!d_labels_1drop || !d_labels_ndrop) return fail(e, PNP_ERR_ARG, "label outputs are null");
     if (p.groups_cap < 2) {                     // arrays sized for one group only: same results, two passes
-        int r = pnp_postprocess(e, d_gradcam_1drop, T, threshold, 1, 3, d_labels_1drop, d_hist_1drop, n_class, stream);
+        int r = pnp_postprocess(e, d_gradcam_1drop, T, threshold, scale01_mask & 1, 3, d_labels_1drop, d_hist_1drop, n_class, stream);
         if (r) return r;
-        return pnp_postprocess(e, d_gradcam_ndrop, T, threshold, 0, 3, d_labels_ndrop, d_hist_ndrop, n_class, stream);
+        return pnp_postprocess(e, d_gradcam_ndrop, T, threshold, (scale01_mask >> 1) & 1, 3, d_labels_ndrop, d_hist_ndrop, n_class, stream);
     }
     hipStream_t s = (hipStream_t)stream;
     for (int grp = 0; grp < 2; grp++) {
         int r = pnp_merge_tokens(e, grp == 0 ? d_gradcam_1drop : d_gradcam_ndrop, T, stream);
         if (r) return r;
-        r = pnp_threshold_upsample(e, threshold, grp == 0 ? 1 : 0, stream);      // Scale_0_1 in the 1-drop branch only
+        r = pnp_threshold_upsample(e, threshold, (scale01_mask >> grp) & 1, stream);   // PnP.py: Scale_0_1 in the 1-drop branch only; PnPc.py: both
         if (r) return r;
         r = pnp_blur_minmax(e, stream);
         if (r) return r;
@@ -1205,6 +1258,7 @@ extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, siz
     auto& p = e->post;
     auto set = [&](void* ptr, size_t b) { *d_ptr = ptr; *bytes = b; return PNP_OK; };
     if (n == "image_embeds") return set(e->emb32, B * e->N * (size_t)e->D * 4);
+    if (n == "image_embeds_t") return set(e->embT, B * e->N * (size_t)e->D * e->esz);
     if (n == "x") return set(e->x, B * e->N * (size_t)e->D * 4);
     if (n == "P") return set(e->ta[e->SL].Pc, B * e->nh * L * (size_t)e->Nst * 4);
     if (n == "dP") return set(e->dPc, B * e->nh * L * (size_t)e->Nst * 4);
@@ -1238,6 +1292,28 @@ extern "C" int pnp_profile_enable(pnp_engine* e, int32_t on) {
     pf.used = 0;
     pf.launches = 0;
     pf.flops = 0;
+    e->crf_prof.on = on != 0;
+    e->crf_prof.used = 0;
+    e->crf_prof.launches = 0;
+    e->crf_prof.work = 0;
+    return PNP_OK;
+}
+
+extern "C" int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* launches, double* work, double* ms) {
+    if (!e || !launches || !work || !ms) return PNP_ERR_ARG;
+    if (stage == 0) return pnp_profile_read(e, launches, work, ms);
+    if (stage != 1) return fail(e, PNP_ERR_ARG, "unknown profile stage %d", stage);
+    auto& pf = e->crf_prof;
+    double total = 0;
+    for (int i = 0; i < pf.used; i++) {
+        HIPCHK(e, hipEventSynchronize(pf.ev1[i]));
+        float t = 0;
+        HIPCHK(e, hipEventElapsedTime(&t, pf.ev0[i], pf.ev1[i]));
+        total += t;
+    }
+    *launches = pf.launches;
+    *work = pf.work;
+    *ms = total;
     return PNP_OK;
 }
 

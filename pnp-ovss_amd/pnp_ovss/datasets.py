@@ -8,7 +8,11 @@ across ranks like `DataLoader(..., sampler=DistributedSampler(dataset))` (Load_d
   psc        Dataset.py:889-991 (same transform), Pascal-Context 59 classes (Load_datasets.py:30-44)
   ade20k     Dataset.py:1181-1296 (PIL *bilinear* resize, ToTensor only), Load_datasets.py:60-104 (150 classes, names
              with blanks removed, validation.odgt list), PnP.py:917-923 / 945-952 (GT / RGB by "ADE_val_%08d")
-COCO (PnP_OVSS_0514_updated_segmentation_coco.py, pycocotools) is the remaining loader.
+  coco_object / coco_stuff   the COCO driver (PnPc.py = PnP_OVSS_0514_updated_segmentation_coco.py): Dataset.py:1373-1491
+             (same bicubic + CLIP-normalise transform), categories / image list / instance annotations read from the
+             annotation JSON with the standard library (pycocotools' COCO index: PnPc.py:1376-1400, Dataset.py:1341-1345),
+             PnPc.py:1095-1125 (GT: instance masks painted in annotation order for coco_object -- `coco_mask.ann_to_mask`
+             restates pycocotools' annToMask --, stuff PNG + 1 with 255 -> 0 for coco_stuff), PnPc.py:1127-1138 (RGB)
 """
 import json
 import os
@@ -39,6 +43,7 @@ ADE_NAMES = ("wall,building,sky,floor,tree,ceiling,road,bed,windowpane,grass,cab
 class _Base:
     max_text_len = 64
     max_channels = 24
+    class_ids = None          # COCO: cats[j]['id'] (labels / confusion matrix are in category-id space)
 
     def __init__(self, args, rank, world_size, cats):
         self.args, self.rank, self.world = args, rank, world_size
@@ -96,6 +101,8 @@ class SyntheticDataset(_Base):
 
 class VocLikeDataset(_Base):
     def __init__(self, args, rank, world_size, kind):
+        if kind == "psc":                                        # 59 classes: up to 59 channels, ~2.4 word pieces per name
+            self.max_channels, self.max_text_len = 60, 160
         from PIL import Image                                    # noqa: F401  (fail early if missing)
         cats = dict(host.VOC_CATS) if kind == "voc" else {i + 1: n for i, n in enumerate(PSC_NAMES)}
         super().__init__(args, rank, world_size, cats)
@@ -166,32 +173,110 @@ class Ade20kDataset(_Base):
         return self.gpt.lookup(img_id, self.nms)
 
 
+class CocoDataset(_Base):
+    """`--data_type coco_object | coco_stuff` (the reference's second driver script).  Everything pycocotools' COCO
+    object provides to that driver is read from the two annotation files with `json`: `cats` in file order
+    (loadCats(getCatIds()), PnPc.py:1383-1395), the image list in file order (Dataset.py:1345), per-image
+    instance annotations (PnPc.py:1100-1110)."""
+    max_text_len = 192
+    max_channels = 96
+
+    def __init__(self, args, rank, world_size, kind):
+        from PIL import Image                                    # noqa: F401
+        home = args.home_dir
+        with open(f"{home}/coco/annotations/instances_val2017.json") as f:
+            thing = json.load(f)
+        cats = [{"id": c["id"], "name": c["name"]} for c in thing["categories"]]
+        if kind == "coco_stuff":
+            with open(f"{home}/coco/annotations/stuff_val2017.json") as f:
+                cats += [{"id": c["id"], "name": c["name"]} for c in json.load(f)["categories"]]
+            self.max_channels = 184
+        self.kind = kind
+        self.rank, self.world, self.args = rank, world_size, args
+        self.cats = cats                                          # list of dicts, like the reference's `cats`
+        self.nms = host.coco_class_names(cats)
+        self.class_ids = [c["id"] for c in cats]
+        n = host.coco_n_class(kind)
+        self.total_hist = np.zeros((n, n), dtype=np.float64)
+        self.images = thing["images"]
+        self.anns = {}
+        if kind == "coco_object":
+            for a in thing["annotations"]:                        # pycocotools imgToAnns: file order per image
+                self.anns.setdefault(a["image_id"], []).append(a)
+        self.gpt = host.GptClassTable(f"{home}/GPT4o_classification/{kind}_classification_noboundary.json", kind)
+        self.max_pixels = 640 * 640
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        from . import coco_mask
+        rec = self.images[i]
+        home = self.args.home_dir
+        org = np.asarray(Image.open(f"{home}/coco/images/val2017/{rec['file_name']}").convert("RGB"))
+        if self.kind == "coco_object":                            # PnPc.py:1099-1110: first annotation wins a pixel
+            gt = np.zeros((rec["height"], rec["width"]), dtype=np.float32)
+            for a in self.anns.get(rec["id"], []):
+                m = coco_mask.ann_to_mask(a, rec["height"], rec["width"])
+                gt[np.logical_and(m, gt == 0)] = a["category_id"]
+        else:                                                     # PnPc.py:1112-1122
+            gt = np.float32(Image.open(f"{home}/coco_stuff164k/annotations/val2017/{int(rec['id']):012d}.png"))
+            gt = np.where(gt == 255, np.float32(0), gt + 1).astype(np.float32)
+        return None, int(rec["id"]), org, gt
+
+    def predicted_classes(self, img_id):
+        return self.gpt.lookup(img_id, self.nms, self.cats)
+
+
 def prefetch(iterable, depth=2):
     """Run `iterable` in a background thread, `depth` items ahead: JPEG decode / ground-truth loading / the device-side
     resize of batch i+1 overlap the model and CRF work of batch i (the reference's DataLoader runs with
-    num_workers=0 on the main thread, PnP.py:61).  Exceptions of the producer are re-raised in the consumer."""
+    num_workers=0 on the main thread, PnP.py:61).  Exceptions of the producer are re-raised in the consumer; when the
+    consumer stops early (break, exception, generator close) the producer is told to stop and joined, so no thread
+    is left blocked on the queue holding device tensors."""
     import queue
     import threading
     q = queue.Queue(maxsize=max(1, depth))
     end = object()
+    stop = threading.Event()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def work():
         try:
             for item in iterable:
-                q.put(item)
-            q.put(end)
+                if not put(item):
+                    return
+            put(end)
         except BaseException as exc:       # noqa: BLE001  (handed to the consumer)
-            q.put(exc)
+            put(exc)
 
     t = threading.Thread(target=work, daemon=True)
     t.start()
-    while True:
-        item = q.get()
-        if item is end:
-            return
-        if isinstance(item, BaseException):
-            raise item
-        yield item
+    try:
+        while True:
+            item = q.get()
+            if item is end:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        while True:                        # unblock a producer waiting in put()
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                break
+        t.join(timeout=30)
 
 
 def make_dataset(args, rank, world_size):
@@ -201,4 +286,6 @@ def make_dataset(args, rank, world_size):
         return VocLikeDataset(args, rank, world_size, args.data_type)
     if args.data_type == "ade20k":
         return Ade20kDataset(args, rank, world_size)
-    raise SystemExit(f"--data_type {args.data_type!r}: supported here: synthetic, voc, psc, ade20k (the COCO driver is next)")
+    if args.data_type in ("coco_object", "coco_stuff"):
+        return CocoDataset(args, rank, world_size, args.data_type)
+    raise SystemExit(f"--data_type {args.data_type!r}: supported: synthetic, voc, psc, ade20k, coco_object, coco_stuff")

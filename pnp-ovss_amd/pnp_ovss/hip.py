@@ -55,6 +55,7 @@ def load_library():
         "pnp_load_weight": (i32, [vp, C.c_char_p, vp, C.POINTER(i64), i32, i32]),
         "pnp_finalize_weights": (i32, [vp]),
         "pnp_vit_forward": (i32, [vp, vp, vp, i32, vp]),
+        "pnp_cross_kv": (i32, [vp, i32, vp]),
         "pnp_text_forward_xattn": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
         "pnp_xattn_grad": (i32, [vp, i32, i32, vp]),
         "pnp_gradcam_gather": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
@@ -69,10 +70,11 @@ def load_library():
         "pnp_densecrf": (i32, [vp, i32, f32, f32, f32, f32, f32, vp]),
         "pnp_remap_hist": (i32, [vp, i32, vp, vp, i32, vp]),
         "pnp_postprocess": (i32, [vp, vp, i32, f32, i32, i32, vp, vp, i32, vp]),
-        "pnp_postprocess_pair": (i32, [vp, vp, vp, i32, f32, vp, vp, vp, vp, i32, vp]),
+        "pnp_postprocess_pair": (i32, [vp, vp, vp, i32, f32, i32, vp, vp, vp, vp, i32, vp]),
         "pnp_get_buffer": (i32, [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]),
         "pnp_profile_enable": (i32, [vp, i32]),
         "pnp_profile_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "pnp_profile_read_stage": (i32, [vp, i32, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "pnp_op_gemm": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp]),
         "pnp_op_gemm_ex": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, vp]),
         "pnp_op_gemm_tokcols": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
@@ -95,7 +97,8 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_finalize_weights", "pnp_vit_forward", "pnp_text_forward_xattn", "pnp_xattn_grad",
             "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
-            "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images"]
+            "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images",
+            "pnp_cross_kv", "pnp_profile_read_stage"]
 
 
 class _DevView:
@@ -282,6 +285,9 @@ class Engine:
         B = images.shape[0]
         self._chk(self.lib.pnp_vit_forward(self.h, _ptr(images), _ptr(dropped), B, _stream()), "pnp_vit_forward")
 
+    def cross_kv(self, B):
+        self._chk(self.lib.pnp_cross_kv(self.h, B, _stream()), "pnp_cross_kv")
+
     def text_forward(self, ids, mask, L):
         B, ld = ids.shape
         logits = torch.empty(B, 2, device=self.device, dtype=torch.float32)
@@ -392,15 +398,18 @@ class Engine:
                   "pnp_postprocess")
         return labels
 
-    def postprocess_pair(self, gradcam_1drop, gradcam_ndrop, threshold, n_class=0, hist_1drop=None, hist_ndrop=None):
-        """Both "blur+crf" branches of a batch (1-drop with Scale_0_1, N-drop without) in one DenseCRF run;
-        returns (labels_1drop, labels_ndrop), identical to two postprocess() calls."""
+    def postprocess_pair(self, gradcam_1drop, gradcam_ndrop, threshold, n_class=0, hist_1drop=None, hist_ndrop=None,
+                         scale01=(True, False)):
+        """Both "blur+crf" branches of a batch in one DenseCRF run; returns (labels_1drop, labels_ndrop), identical
+        to two postprocess() calls.  scale01 = Scale_0_1 on (1-drop, N-drop): (True, False) is PnP.py, the COCO
+        driver scales both."""
         total = sum(h * w for h, w in self._post_sizes)
         l1 = torch.empty(total, device=self.device, dtype=torch.uint8)
         ln = torch.empty(total, device=self.device, dtype=torch.uint8)
         assert gradcam_1drop.shape == gradcam_ndrop.shape
         self._chk(self.lib.pnp_postprocess_pair(self.h, _ptr(gradcam_1drop), _ptr(gradcam_ndrop), gradcam_1drop.shape[1],
-                                                float(threshold), _ptr(l1), _ptr(hist_1drop), _ptr(ln), _ptr(hist_ndrop),
+                                                float(threshold), (1 if scale01[0] else 0) | (2 if scale01[1] else 0),
+                                                _ptr(l1), _ptr(hist_1drop), _ptr(ln), _ptr(hist_ndrop),
                                                 n_class, _stream()), "pnp_postprocess_pair")
         return l1, ln
 
@@ -420,6 +429,12 @@ class Engine:
         self._chk(self.lib.pnp_profile_read(self.h, C.byref(n), C.byref(fl), C.byref(ms)), "pnp_profile_read")
         return n.value, fl.value, ms.value
 
+    def profile_read_stage(self, stage):
+        """stage 0: dense GEMMs (launches, FLOPs, ms); stage 1: DenseCRF mean-field (runs, algorithmic bytes, ms)."""
+        n, w, ms = C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.pnp_profile_read_stage(self.h, stage, C.byref(n), C.byref(w), C.byref(ms)), "pnp_profile_read_stage")
+        return n.value, w.value, ms.value
+
     # ------------------------------------------------------------------ introspection
     def buffer(self, name, dtype=torch.float32):
         p, n = C.c_void_p(), C.c_size_t()
@@ -427,6 +442,12 @@ class Engine:
         item = torch.empty(0, dtype=dtype).element_size()
         typestr = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1"}[dtype]
         return torch.as_tensor(_DevView(p.value, (n.value // item,), typestr), device=self.device)
+
+    def buffer_ptr(self, name):
+        """(device pointer, bytes) of a named internal buffer."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.pnp_get_buffer(self.h, name.encode(), C.byref(p), C.byref(n)), f"pnp_get_buffer({name})")
+        return p.value, n.value
 
     def post_maps(self, name="maps"):
         """Per-image (K,H,W) views of an internal post-process map buffer."""

@@ -8,6 +8,8 @@ names and argument meaning.  PnP.py = PnP_OVSS_0514_updated_segmentation.py.
   background rule          PnP.py:373-379 -> has_background
   DistributedSampler split LD.py:25 -> shard_indices
   scores / mIoU            PnP.py:1115-1146, Calculate_mIoU.py:204-256 -> scores_from_hist
+COCO driver (PnPc.py = PnP_OVSS_0514_updated_segmentation_coco.py): parse_gpt_classes_coco (:858-963), the
+background rule of :446-450 / :470-473 and the cats[..]['id'] remap of :458-463 / :482-489 (remap_lut(class_ids=)).
 """
 import json
 
@@ -38,6 +40,39 @@ def parse_gpt_classes(per_img_cls: str, nms):
     return best, names, "A picture of " + " ".join(names)
 
 
+def parse_gpt_classes_coco(per_img_cls: str, cats, nms, data_type="coco_object"):
+    """COCO variant (PnPc.py:870-905 coco_object, :918-958 coco_stuff): the number GPT-4o printed is a COCO category
+    id, best_class_idx is its position in `cats` (list of {'id', 'name'}, pycocotools order); ids that are no
+    category are skipped; a string without the probability list keeps every class ("no prob output")."""
+    parts = per_img_cls.replace(']\n\n[', '], [').replace('],\n\n[', '], [').replace('], \n[', '], [ ') \
+        .replace('],\n[', '], [ ').replace(']\n[', '], [ ').strip("][").split("], [")
+    cls_list = parts[0].split(",")
+    if len(parts) == 1 and parts[0] == '':
+        cls_list = ["1: 'person'" for _ in range(len(cls_list))]
+        prob_list = [100 for _ in range(len(cls_list))]
+    elif len(parts) == 1:
+        prob_list = [100 for _ in range(len(cls_list))]
+    else:
+        prob_list = [int(p.split(":")[-1].split("%")[0]) for p in parts[1].split(",")]
+    stuff = data_type == "coco_stuff"
+    if stuff:
+        prob_list = prob_list[:len(cls_list)]
+    ids = []
+    for i, p in enumerate(prob_list):
+        if p > 70:
+            try:
+                ids.append(int(cls_list[i].split(":")[0]))
+            except Exception:              # noqa: BLE001
+                if not stuff:              # only the coco_stuff branch swallows malformed entries (:943-946)
+                    raise
+    pos = {c["id"]: j for j, c in reversed(list(enumerate(cats)))}      # first match wins, like the reference loop
+    best = [pos[v] for v in ids if v in pos]
+    names = [nms[j] for j in best]
+    if not best:
+        best, names = [0], [nms[0]]
+    return best, names, "A picture of " + " ".join(names)
+
+
 class GptClassTable:
     """One of GPT4o_classification/*.json, read once (the reference re-opens it per image)."""
 
@@ -46,7 +81,9 @@ class GptClassTable:
             self.table = json.load(f)
         self.data_type = data_type
 
-    def lookup(self, img_id, nms):
+    def lookup(self, img_id, nms, cats=None):
+        if self.data_type.startswith("coco"):
+            return parse_gpt_classes_coco(self.table[str(int(img_id)).rjust(12, "0")], cats, nms, self.data_type)
         key = "ADE_val_" + str(img_id).rjust(8, "0") if self.data_type == "ade20k" else str(img_id)
         return parse_gpt_classes(self.table[key], nms)
 
@@ -90,22 +127,35 @@ def caption_pieces(tokenizer, input_ids_row):
 
 def has_background(data_type, n_selected):
     """PnP.py:373-379: object datasets always get a background channel, context datasets only when
-    fewer than 3 classes were selected."""
-    return data_type == "voc" or n_selected < 3
+    fewer than 3 classes were selected.  COCO (PnPc.py:446-450 / :470-473): coco_object always,
+    coco_stuff like the context datasets."""
+    return data_type in ("voc", "coco_object") or n_selected < 3
 
 
-def remap_lut(best_class_idx, with_background, n_channels):
+def remap_lut(best_class_idx, with_background, n_channels, class_ids=None):
     """Fold the in-place, descending, collision-prone remap of PnP.py:390-399 into a table
-    argmax index -> dataset class id (every pixel value follows the same chain of rewrites)."""
+    argmax index -> dataset class id (every pixel value follows the same chain of rewrites).
+    COCO (PnPc.py:458-463, :482-489, :549-556, :577-584): the target is cats[best_class_idx[i]]['id'],
+    passed as class_ids[j] = cats[j]['id']."""
     lut = []
     for v0 in range(n_channels):
         v = v0
         for i in range(len(best_class_idx) - 1, -1, -1):
             src = i + 1 if with_background else i
             if v == src:
-                v = best_class_idx[i] + 1
+                v = best_class_idx[i] + 1 if class_ids is None else class_ids[best_class_idx[i]]
         lut.append(int(v))
     return lut
+
+
+def coco_n_class(data_type):
+    """PnPc.py:597-600: the confusion matrix spans category ids, not positions."""
+    return 91 if data_type == "coco_object" else 183
+
+
+def coco_class_names(cats):
+    """PnPc.py:1399-1400: class names with blanks and dashes removed."""
+    return ["".join("".join(c["name"].split(" ")).split("-")) for c in cats]
 
 
 def shard_indices(n, rank, world_size, seed=0, shuffle=True):

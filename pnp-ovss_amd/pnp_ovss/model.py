@@ -213,13 +213,24 @@ def build_model(model_type="large", img_size=336, device=0, max_batch=35, max_te
 
 
 class Segmenter:
-    """Device work of save_img_union_attention (PnP.py:290-521) for one batch: drop loop, merge,
-    threshold/upsample, blur, CRF, argmax/remap, histogram."""
+    """Device work of save_img_union_attention (PnP.py:290-521; COCO driver PnPc.py:338-642) for one batch: drop
+    loop, merge, threshold/upsample, blur, CRF, argmax/remap, histogram.
+
+    data_type "voc" | "psc" | "ade20k": PnP.py rules (both branches; Scale_0_1 on the 1-drop branch only; labels are
+    class positions + 1).  "coco_object" | "coco_stuff": the COCO driver's rules -- the 1-drop branch runs only when
+    drop_iter < 3 (PnPc.py:420), Scale_0_1 on both branches (:436, :527), background rule of :446-450 / :470-473,
+    labels are COCO category ids (`class_ids[j]` = cats[j]['id'], :458-463 ...), n_class 91 / 183 (:597-600)."""
 
     def __init__(self, model, data_type, n_class, threshold=0.15, postprocess="blur+crf", max_pixels_per_image=600 * 600,
-                 max_channels=24, crf_chunk=0):
+                 max_channels=24, crf_chunk=0, class_ids=None):
         self.m = model.module if hasattr(model, "module") else model
         self.data_type, self.n_class, self.threshold, self.mode = data_type, n_class, threshold, postprocess
+        self.coco = data_type.startswith("coco")
+        self.class_ids = list(class_ids) if class_ids is not None else None
+        if self.coco and self.class_ids is None:
+            raise ValueError("COCO data types need class_ids (cats[j]['id'])")
+        if n_class > 256:
+            raise ValueError("label maps are uint8: at most 256 classes")
         eng = self.m.engine
         eng.post_reserve(eng.max_batch, eng.max_batch * max_pixels_per_image, max_pixels_per_image, max_channels, crf_chunk)
         self.hist_1drop = torch.zeros(n_class * n_class, device=eng.device, dtype=torch.int64)
@@ -230,6 +241,9 @@ class Segmenter:
         dev = eng.device
         tok500 = m.tokenizer(captions, padding="max_length", max_length=500, return_tensors="pt")
         g0, agg = drop_loop(args, m, tok500, imgs_in, captions)
+        if self.coco and int(args.drop_iter) >= 3:
+            run_1drop = False
+        scale01 = (True, self.coco)                                 # Scale_0_1 on (1-drop, N-drop)
         ids = tok500.input_ids.numpy()
         sizes = [(int(x.shape[0]), int(x.shape[1])) for x in org_images]
         plans, luts, bgs = [], [], []
@@ -237,7 +251,7 @@ class Segmenter:
             pieces = host.caption_pieces(m.tokenizer, ids[i])
             bg = host.has_background(self.data_type, len(best))
             plans.append(host.merge_plan(pieces, len(best)))
-            luts.append(host.remap_lut(best, bg, len(best) + int(bg)))
+            luts.append(host.remap_lut(best, bg, len(best) + int(bg), self.class_ids))
             bgs.append(bg)
         rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(x, dtype=np.uint8).reshape(-1) for x in org_images])).to(dev)
         gt = None
@@ -247,10 +261,10 @@ class Segmenter:
         out1 = outn = None
         if run_1drop and agg is not None and self.mode == "blur+crf":
             # both branches share the image lattices: one DenseCRF run over two channel groups (same results)
-            l1, ln = eng.postprocess_pair(g0, agg, self.threshold, self.n_class, self.hist_1drop, self.hist_ndrop)
+            l1, ln = eng.postprocess_pair(g0, agg, self.threshold, self.n_class, self.hist_1drop, self.hist_ndrop, scale01)
             return eng.split_labels(l1), eng.split_labels(ln)
         if run_1drop or agg is None:
-            out1 = eng.split_labels(eng.postprocess(g0, self.threshold, True, self.mode, self.n_class, self.hist_1drop))
+            out1 = eng.split_labels(eng.postprocess(g0, self.threshold, scale01[0], self.mode, self.n_class, self.hist_1drop))
         if agg is not None:
-            outn = eng.split_labels(eng.postprocess(agg, self.threshold, False, self.mode, self.n_class, self.hist_ndrop))
+            outn = eng.split_labels(eng.postprocess(agg, self.threshold, scale01[1], self.mode, self.n_class, self.hist_ndrop))
         return out1, outn

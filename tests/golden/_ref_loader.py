@@ -16,6 +16,7 @@ import torch.nn as nn
 REF = "/root/reference"
 REF_B = REF + "/Files to replace for BLIP/"
 PNP = REF + "/PnP_OVSS_0514_updated_segmentation.py"
+PNPC = REF + "/PnP_OVSS_0514_updated_segmentation_coco.py"
 
 
 def _mod(name, **attrs):
@@ -146,15 +147,15 @@ def build_reference_model(cfg, state_dict_np, tokenizer):
     return m, itm
 
 
-def load_driver_functions(names, extra_globals):
-    """exec the named top-level functions of the reference driver script (never copied: read from
+def load_driver_functions(names, extra_globals, path=PNP):
+    """exec the named top-level functions of a reference driver script (never copied: read from
     the read-only file at generation time) into a fresh namespace."""
-    src = open(PNP).read()
+    src = open(path).read()
     tree = ast.parse(src)
     ns = dict(extra_globals)
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:
-            code = compile(ast.Module(body=[node], type_ignores=[]), PNP, "exec")
+            code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
             exec(code, ns)
     missing = [n for n in names if n not in ns]
     assert not missing, missing

@@ -12,6 +12,9 @@ Fixtures (inputs are regenerated from seeds by pnp_ovss.synth; only outputs are 
   merge_tokens.npz    Mean_over_filtered_label_tokens on split / unsplit captions
   pipeline_voc.npz    save_img_union_attention end to end (blur / no post-process; CRF is not
   pipeline_psc.npz    importable here -> parity unpinned for CRF), hist .npy contents
+  pipeline_coco_object.npz / pipeline_coco_stuff.npz   the COCO driver's save_img_union_attention
+                      (PnP_OVSS_0514_updated_segmentation_coco.py) at drop_iter 4 (N-drop only) and 2 (both branches)
+  gpt_parse_coco.json the COCO driver's Load_predicted_classes on sampled strings (category id -> cats position)
   gpt_parse.json      Load_predicted_classes on sampled GPT-4o strings of the shipped JSON files
   blur_cases.npz      `blurring` (scipy gaussian_filter + min-max) incl. non-square and NaN cases
   hist_cases.npz      _fast_hist / scores on hand-made label maps
@@ -253,6 +256,159 @@ def gen_pipeline_psc():
     _gen_pipeline("psc", ["2008_000009", "2008_000003", "2008_000032"], _psc_cats(), "pipeline_psc.npz")
 
 
+# COCO category tables (pycocotools loadCats order = ascending id).  Data, not code: ids / names of
+# instances_val2017.json + stuff_val2017.json; every (id, name) pair that occurs in the reference's shipped
+# GPT4o_classification/coco_*_classification_noboundary.json strings is cross-checked below.
+COCO_THINGS = {1: "person", 2: "bicycle", 3: "car", 4: "motorcycle", 5: "airplane", 6: "bus", 7: "train", 8: "truck", 9: "boat",
+               10: "traffic light", 11: "fire hydrant", 13: "stop sign", 14: "parking meter", 15: "bench", 16: "bird", 17: "cat",
+               18: "dog", 19: "horse", 20: "sheep", 21: "cow", 22: "elephant", 23: "bear", 24: "zebra", 25: "giraffe",
+               27: "backpack", 28: "umbrella", 31: "handbag", 32: "tie", 33: "suitcase", 34: "frisbee", 35: "skis",
+               36: "snowboard", 37: "sports ball", 38: "kite", 39: "baseball bat", 40: "baseball glove", 41: "skateboard",
+               42: "surfboard", 43: "tennis racket", 44: "bottle", 46: "wine glass", 47: "cup", 48: "fork", 49: "knife",
+               50: "spoon", 51: "bowl", 52: "banana", 53: "apple", 54: "sandwich", 55: "orange", 56: "broccoli", 57: "carrot",
+               58: "hot dog", 59: "pizza", 60: "donut", 61: "cake", 62: "chair", 63: "couch", 64: "potted plant", 65: "bed",
+               67: "dining table", 70: "toilet", 72: "tv", 73: "laptop", 74: "mouse", 75: "remote", 76: "keyboard",
+               77: "cell phone", 78: "microwave", 79: "oven", 80: "toaster", 81: "sink", 82: "refrigerator", 84: "book",
+               85: "clock", 86: "vase", 87: "scissors", 88: "teddy bear", 89: "hair drier", 90: "toothbrush"}
+COCO_STUFF = {92: "banner", 93: "blanket", 94: "branch", 95: "bridge", 96: "building-other", 97: "bush", 98: "cabinet", 99: "cage",
+              100: "cardboard", 101: "carpet", 102: "ceiling-other", 103: "ceiling-tile", 104: "cloth", 105: "clothes",
+              106: "clouds", 107: "counter", 108: "cupboard", 109: "curtain", 110: "desk-stuff", 111: "dirt", 112: "door-stuff",
+              113: "fence", 114: "floor-marble", 115: "floor-other", 116: "floor-stone", 117: "floor-tile", 118: "floor-wood",
+              119: "flower", 120: "fog", 121: "food-other", 122: "fruit", 123: "furniture-other", 124: "grass", 125: "gravel",
+              126: "ground-other", 127: "hill", 128: "house", 129: "leaves", 130: "light", 131: "mat", 132: "metal",
+              133: "mirror-stuff", 134: "moss", 135: "mountain", 136: "mud", 137: "napkin", 138: "net", 139: "paper",
+              140: "pavement", 141: "pillow", 142: "plant-other", 143: "plastic", 144: "platform", 145: "playingfield",
+              146: "railing", 147: "railroad", 148: "river", 149: "road", 150: "rock", 151: "roof", 152: "rug", 153: "salad",
+              154: "sand", 155: "sea", 156: "shelf", 157: "sky-other", 158: "skyscraper", 159: "snow", 160: "solid-other",
+              161: "stairs", 162: "stone", 163: "straw", 164: "structural-other", 165: "table", 166: "tent",
+              167: "textile-other", 168: "towel", 169: "tree", 170: "vegetable", 171: "wall-brick", 172: "wall-concrete",
+              173: "wall-other", 174: "wall-panel", 175: "wall-stone", 176: "wall-tile", 177: "wall-wood", 178: "water-other",
+              179: "waterdrops", 180: "window-blind", 181: "window-other", 182: "wood", 183: "other"}
+
+
+def _coco_cats(data_type):
+    """cats / nms as the COCO driver's main() builds them (PnP..._coco.py:1381-1400)."""
+    things = [{"id": i, "name": n} for i, n in COCO_THINGS.items()]
+    stuff = [{"id": i, "name": n} for i, n in COCO_STUFF.items()]
+    cats = things + stuff if data_type == "coco_stuff" else things
+    nms = [c["name"] for c in cats]
+    for i, classname in enumerate(nms):
+        nms[i] = "".join("".join(classname.split(" ")).split("-"))
+    return cats, nms
+
+
+def _check_coco_tables():
+    import re
+    import collections
+    for dt, table in (("coco_object", COCO_THINGS), ("coco_stuff", {**COCO_THINGS, **COCO_STUFF})):
+        d = json.load(open(RL.REF + f"/GPT4o_classification/{dt}_classification_noboundary.json"))
+        seen = collections.defaultdict(collections.Counter)
+        for v in d.values():
+            for m in re.finditer(r"(\d+):\s*'?([A-Za-z \-]+)'?", v.split("], [")[0]):
+                seen[int(m.group(1))][m.group(2).strip()] += 1
+        for i, names in seen.items():
+            if i in table:
+                assert names.most_common(1)[0][0] == table[i], (dt, i, names.most_common(2), table[i])
+
+
+def _gen_pipeline_coco(data_type, img_ids, fname):
+    """The COCO driver's save_img_union_attention end to end on 3 synthetic images (GPT-4o strings: the shipped
+    JSON entries of `img_ids`).  drop_iter 4 -> N-drop branch only (with Scale_0_1); drop_iter 2 -> both."""
+    _check_coco_tables()
+    from PIL import Image
+    cfg = C.blip_itm_small(128)
+    m, itm, tok = _model(cfg, seed=4)
+    B = 3
+    _, imgs = synth.synth_images(B, cfg.img_size, seed=6)
+    sizes = [(90, 120), (128, 128), (75, 100)]
+    rng = np.random.default_rng(99)
+    org = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    cats, nms = _coco_cats(data_type)
+    n_class = 91 if data_type == "coco_object" else 183
+    gts = [rng.integers(0, n_class, size=(h, w)).astype(np.float32) for h, w in sizes]
+    names = ["save_img_union_attention", "Inference_BLIP_filteredcaption", "Load_predicted_classes",
+             "Mean_over_filtered_label_tokens", "postprocess", "blurring", "Scale_0_1", "_fast_hist", "scores",
+             "getClassName", "print_iou"]
+    S = cfg.img_size
+    ns = RL.load_driver_functions(names, _driver_ns(itm, dict(Image=Image, getAttMap=lambda *a, **k: np.zeros((S, S, 3)),
+                                                              Draw_Segmentation_map=lambda *a, **k: None)), path=RL.PNPC)
+    ns["load_OrgImage"] = lambda args, ids, coco: org
+    ns["Load_GroundTruth"] = lambda args, ids, coco: gts
+    out = {}
+    real_sc = ns["scores"]
+    real_pp = ns["postprocess"]
+    for di, pp in ((4, "blur"), (4, None), (2, "blur")):
+        rec, labs = [], []
+        if pp:
+            def spy(args, pred, org_img_list, label_trues, img, _r=rec, _f=real_pp):
+                _r.append(pred.detach().clone().numpy().astype(np.float32))
+                return _f(args, pred, org_img_list, label_trues, img)
+            ns["postprocess"] = spy
+
+        def spy_scores(lt, lp, cats_, n_class, _l=labs):
+            _l.append([np.array(x).astype(np.uint8) for x in lp])
+            return real_sc(lt, lp, cats_, n_class)
+        ns["scores"] = spy_scores
+        tmp = tempfile.mkdtemp()
+        args = argparse.Namespace(img_size=S, drop_iter=di, max_att_block_num=8, prune_att_head="9",
+                                  del_patch_num="sort_thresh005", data_type=data_type, postprocess=pp, threshold=0.15,
+                                  home_dir=RL.REF, save_path=tmp, in_the_wild=False)
+        tok500 = tok(["x"] * B, padding="max_length", max_length=500, return_tensors="pt")
+        norm_imgs = torch.zeros(B, S, S, 3)
+        with np.errstate(all="ignore"):
+            ns["save_img_union_attention"](None, RL.DDPLike(m), torch.from_numpy(imgs.copy()), None, args, [[]] * B, img_ids, di,
+                                           norm_imgs, None, cats, nms, tok500, "cpu", att_head=9, max_block_num=8)
+        ns["postprocess"] = real_pp
+        ns["scores"] = real_sc
+        tag = f"d{di}_{pp or 'none'}"
+        branches = ("1drop", "ndrop") if di < 3 else ("ndrop",)
+        dirs = {"1drop": "hist_withfiltered_caption", "ndrop": "all_drop_hist_with_filtered_caption"}
+        for br, name in enumerate(branches):
+            out[f"hist_{name}_{tag}"] = np.load(os.path.join(tmp, dirs[name], f"img_{img_ids[0]}_max_blocknum_8_atthead_9.npy"))
+            for i in range(B):
+                out[f"labels_{name}_{tag}_{i}"] = labs[br][i]
+                if pp:
+                    out[f"prepost_{name}_{tag}_{i}"] = rec[br * B + i]
+        if di >= 3:
+            assert not os.path.exists(os.path.join(tmp, dirs["1drop"], f"img_{img_ids[0]}_max_blocknum_8_atthead_9.npy"))
+    gpt = json.load(open(RL.REF + f"/GPT4o_classification/{data_type}_classification_noboundary.json"))
+    keys = [str(int(i)).rjust(12, "0") for i in img_ids]
+    np.savez_compressed(os.path.join(HERE, fname), cfg=json.dumps(cfg.as_dict()), weight_seed=4, image_seed=6,
+                        img_ids=np.array(img_ids), gpt=json.dumps({k: gpt[k] for k in keys}), cats=json.dumps(cats),
+                        data_type=data_type, sizes=np.array(sizes), org_seed=99, n_class=n_class, **out)
+    print(fname, {k: getattr(v, "shape", None) for k, v in out.items()})
+
+
+def gen_pipeline_coco_object():
+    _gen_pipeline_coco("coco_object", [397133, 252219, 37777], "pipeline_coco_object.npz")
+
+
+def gen_pipeline_coco_stuff():
+    _gen_pipeline_coco("coco_stuff", [397133, 502136, 37777], "pipeline_coco_stuff.npz")
+
+
+def gen_gpt_parse_coco():
+    ns = RL.load_driver_functions(["Load_predicted_classes"], dict(json=json), path=RL.PNPC)
+    res = {}
+    for dt in ("coco_object", "coco_stuff"):
+        cats, nms = _coco_cats(dt)
+        data = json.load(open(RL.REF + f"/GPT4o_classification/{dt}_classification_noboundary.json"))
+        keys = sorted(data.keys())
+        pick = keys[::max(1, len(keys) // 50)][:50]
+        odd = [k for k in keys if ("\n" in data[k] or data[k] == "" or "], [" not in data[k] or "%" not in data[k])][:20]
+        exp = {}
+        for k in sorted(set(pick + odd)):
+            args = argparse.Namespace(home_dir=RL.REF, data_type=dt)
+            try:
+                b, c, cap = ns["Load_predicted_classes"](args, nms, cats, [], [], [], [[]], [int(k)], 0, pred_path=None)
+                exp[k] = {"raw": data[k], "best_class_idx": b[0], "classes": c[0], "caption": cap[0]}
+            except Exception as e:          # noqa: BLE001  (the reference raises on some malformed strings)
+                exp[k] = {"raw": data[k], "error": type(e).__name__}
+        res[dt] = {"cats": cats, "cases": exp}
+    json.dump(res, open(os.path.join(HERE, "gpt_parse_coco.json"), "w"), indent=0)
+    print("gpt_parse_coco:", {k: (len(v["cases"]), sum("error" in c for c in v["cases"].values())) for k, v in res.items()})
+
+
 def gen_gpt_parse():
     ns = RL.load_driver_functions(["Load_predicted_classes"], dict(json=json))
     res = {}
@@ -353,7 +509,9 @@ def gen_preprocess_cases():
 
 
 GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, droploop_small=gen_droploop_small,
-            merge_tokens=gen_merge_tokens, pipeline_voc=gen_pipeline_voc, pipeline_psc=gen_pipeline_psc, gpt_parse=gen_gpt_parse,
+            merge_tokens=gen_merge_tokens, pipeline_voc=gen_pipeline_voc, pipeline_psc=gen_pipeline_psc,
+            pipeline_coco_object=gen_pipeline_coco_object, pipeline_coco_stuff=gen_pipeline_coco_stuff,
+            gpt_parse_coco=gen_gpt_parse_coco, gpt_parse=gen_gpt_parse,
             blur_cases=gen_blur_cases, hist_cases=gen_hist_cases, preprocess_cases=gen_preprocess_cases)
 
 if __name__ == "__main__":

@@ -138,3 +138,38 @@ def test_ade20k_dataset_layout_and_device_preprocess(tmp_path):
         assert np.array_equal(got[j], x), img_id
         best, names, cap = ds.predicted_classes(img_id)
         assert best == [44, 2] and names == ["chestofdrawers", "sky"] and cap == "A picture of chestofdrawers sky"
+
+
+def test_coco_dataset_layout_and_rules(tmp_path):
+    """`--data_type coco_object` on a tiny fake tree laid out as the COCO driver expects (coco/annotations/
+    instances_val2017.json, coco/images/val2017, GPT table keyed by the 12-digit id): categories / image order from the
+    JSON (pycocotools index order), GT painted from instance masks in annotation order with the first annotation
+    winning a pixel (PnP_OVSS_0514_updated_segmentation_coco.py:1099-1110), class positions via cats[..]['id']."""
+    import types
+    from PIL import Image
+    from pnp_ovss import datasets, host
+    (tmp_path / "coco/annotations").mkdir(parents=True)
+    (tmp_path / "coco/images/val2017").mkdir(parents=True)
+    (tmp_path / "GPT4o_classification").mkdir()
+    rng = np.random.default_rng(5)
+    cats = [{"id": 1, "name": "person", "supercategory": "x"}, {"id": 3, "name": "car", "supercategory": "x"},
+            {"id": 10, "name": "traffic light", "supercategory": "x"}]
+    images, anns, table = [], [], {}
+    for k, (iid, (h, w)) in enumerate(((139, (40, 60)), (285, (48, 48)))):
+        Image.fromarray(rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)).save(tmp_path / f"coco/images/val2017/{iid:012d}.jpg", quality=95)
+        images.append({"id": iid, "file_name": f"{iid:012d}.jpg", "height": h, "width": w})
+        anns.append({"id": 10 * k, "image_id": iid, "category_id": 3, "iscrowd": 0, "segmentation": [[2, 1, 10, 1, 10, 6, 2, 6]]})
+        anns.append({"id": 10 * k + 1, "image_id": iid, "category_id": 10, "iscrowd": 0, "segmentation": [[5, 3, 20, 3, 20, 9, 5, 9]]})
+        table[f"{iid:012d}"] = "[10: traffic light, 3: car, 77: cell phone, 1: person], [90, 80, 99, 40]"
+    (tmp_path / "coco/annotations/instances_val2017.json").write_text(json.dumps({"categories": cats, "images": images, "annotations": anns}))
+    (tmp_path / "GPT4o_classification/coco_object_classification_noboundary.json").write_text(json.dumps(table))
+    args = types.SimpleNamespace(home_dir=str(tmp_path), img_size=32, data_type="coco_object")
+    ds = datasets.make_dataset(args, 0, 1)
+    assert ds.nms == ["person", "car", "trafficlight"] and ds.class_ids == [1, 3, 10] and ds.total_hist.shape == (91, 91)
+    (b,) = list(ds.batches(4))
+    assert sorted(b["img_ids"]) == [139, 285] and b["imgs"].shape == (2, 3, 32, 32)
+    gt = b["label_trues"][0]
+    assert gt[1, 2] == 3 and gt[3, 7] == 3 and gt[4, 12] == 10 and gt[0, 0] == 0 and gt[6, 5] == 10      # overlap keeps "car"
+    best, names, cap = ds.predicted_classes(139)
+    assert best == [2, 1] and names == ["trafficlight", "car"] and cap == "A picture of trafficlight car"   # id 77: not a category here
+    assert host.remap_lut(best, True, 3, ds.class_ids) == [0, 10, 3]

@@ -294,13 +294,6 @@ def test_gradcam_small_vs_reference_golden(bf16):
         np.testing.assert_allclose(dP, g["dP7"], rtol=0, atol=3e-4)
 
 
-def test_gradcam_buffers_layout_note():
-    """P / dP stash rows are (B, heads, L, Nst) with L the *call's* L, not max_text_len."""
-    cfg = C.blip_itm_small(64)
-    e = _engine(cfg, 3, False)
-    assert e.cfg.n_img_tokens == 17
-
-
 @pytest.mark.parametrize("bf16", [False, True])
 def test_drop_loop_small_vs_reference_golden(bf16):
     g = _golden("droploop_small.npz")
@@ -323,7 +316,9 @@ def test_drop_loop_small_vs_reference_golden(bf16):
         np.testing.assert_allclose(g0.cpu().numpy(), g["g0_d4"], rtol=0, atol=1e-4)
         np.testing.assert_allclose(agg.cpu().numpy(), g["agg_d4"], rtol=0, atol=4e-4)
     else:
-        assert same >= 3                        # bf16 may reorder near-ties; the first iteration must agree
+        # bf16 is NOT a parity mode (8-bit operands: ~1 % error on image_embeds moves near-tie picks); its divergence
+        # from fp32 is bounded in test_bf16_vs_f32_divergence_is_bounded -- here only sanity of the run
+        assert same >= 3
         assert np.abs(agg.cpu().numpy() - g["agg_d4"]).max() < 0.08 * g["agg_d4"].max()
     g0_1, agg_1, _, _ = e.drop_loop(_dev(imgs), ids, mask, L, 9, 1)
     assert agg_1 is None
@@ -581,6 +576,85 @@ def test_end_to_end_f32_labels_vs_reference_run(fname):
     torch.cuda.synchronize()
     bad = sum(int((got[i].cpu().numpy().astype(np.float32) != ln[i]).sum()) for i in range(B))
     assert bad <= 0.003 * total, bad
+
+
+@pytest.mark.parametrize("fname", ["pipeline_coco_object.npz", "pipeline_coco_stuff.npz"])
+def test_end_to_end_coco_driver_vs_reference_run(fname):
+    """BASELINE config 4 semantics: the product's Segmenter (as the COCO command line drives it) in fp32 mode against
+    the label maps and .npy confusion matrices the reference's COCO driver itself produced
+    (PnP_OVSS_0514_updated_segmentation_coco.py save_img_union_attention; tests/golden/make_golden.py): drop_iter 4 ->
+    N-drop branch only, drop_iter 2 -> both branches, Scale_0_1 on both, background rule, category-id remap, 91 / 183
+    classes.  Only float near-ties between the two best channels may differ."""
+    import argparse
+    from test_oracle_golden import coco_case
+    from pnp_ovss.model import BlipITM, Segmenter
+    g = _golden(fname)
+    c = coco_case(g)
+    cfg, B = c["cfg"], 3
+    n_class = int(g["n_class"])
+    e = _engine(cfg, int(g["weight_seed"]), False, max_batch=4, max_text_len=40)
+    model = BlipITM(cfg, e, c["tok"])
+    segs = {}
+    for di, mode in ((4, "blur"), (4, None), (2, "blur")):
+        if "seg" not in segs:                                   # one reserve per engine
+            segs["seg"] = Segmenter(model, c["data_type"], n_class, threshold=0.15, postprocess=mode,
+                                    max_pixels_per_image=128 * 128, max_channels=16, class_ids=c["class_ids"])
+        seg = segs["seg"]
+        seg.mode = mode
+        seg.hist_1drop.zero_()
+        seg.hist_ndrop.zero_()
+        args = argparse.Namespace(drop_iter=di, prune_att_head="9")
+        l1, ln = seg.run(args, torch.from_numpy(c["imgs"]), c["caps"], c["best"], c["org"], c["gts"])
+        torch.cuda.synchronize()
+        tag = f"d{di}_{mode or 'none'}"
+        assert (l1 is None) == (di >= 3)
+        maps = [m.cpu().numpy() for m in e.post_maps("maps")]                # maps of the last branch run (N-drop)
+        for name, labs, hist in (("1drop", l1, seg.hist_1drop), ("ndrop", ln, seg.hist_ndrop)):
+            if labs is None:
+                continue
+            bad = n = 0
+            for i in range(B):
+                ref = g[f"labels_{name}_{tag}_{i}"]
+                diff = labs[i].cpu().numpy() != ref
+                n += int(diff.sum())
+                if name == "ndrop" and maps[i].shape[0] > 1:
+                    srt = np.sort(maps[i], axis=0)
+                    diff &= ~((srt[-1] - srt[-2]) <= 1e-4 * np.abs(srt[-1]))
+                    bad += int(diff.sum())
+            total = sum(h * w for h, w in c["sizes"])
+            assert bad == 0 and n <= 0.002 * total, (tag, name, bad, n)
+            if n == 0:                                            # same labels -> the saved .npy must be identical
+                np.testing.assert_array_equal(hist.cpu().numpy().reshape(n_class, n_class), g[f"hist_{name}_{tag}"].astype(np.int64))
+            else:
+                assert np.abs(hist.cpu().numpy().reshape(n_class, n_class) - g[f"hist_{name}_{tag}"]).sum() <= 2 * n
+
+
+def test_bf16_vs_f32_divergence_is_bounded():
+    """What the bf16 throughput mode costs in fidelity, with stated bounds (measured on MI355X: tools/precision_probe.py,
+    BLIP-ITM-large, 8 images: image_embeds 1.1 % relative error, selected map 5 %, identical top-10 sets 6 of 8 in
+    iteration 0 falling to 1 of 8 after four iterations, 4.7 % / 10.5 % of 1-drop / N-drop label pixels differ).
+    bf16 operands carry 8 significant bits; the ~1 % error of image_embeds moves near-tie salience picks and nothing
+    on the text side can repair it (same probe: ViT bf16 + everything else fp32 still 4.2 % map error), so the
+    parity mode is fp32 and bf16 is reported as a separate operating point.  This test pins the small-geometry
+    numbers so a regression of the bf16 path is caught: first-iteration picks and map error."""
+    g = _golden("droploop_small.npz")
+    cfg = _cfg(g)
+    _, imgs = synth.synth_images(3, cfg.img_size, seed=int(g["image_seed"]))
+    ids, mask = _dev(g["input_ids"]), _dev(g["attention_mask"])
+    L = int(g["attention_mask"].sum(1).max())
+    out = {}
+    for bf16 in (False, True):
+        e = _engine(cfg, int(g["weight_seed"]), bf16)
+        g0, agg, picks, _ = e.drop_loop(_dev(imgs), ids, mask, L, 9, 4)
+        torch.cuda.synchronize()
+        out[bf16] = (g0.cpu().numpy(), agg.cpu().numpy(), picks.cpu().numpy())
+    (g0f, aggf, pf), (g0b, aggb, pb) = out[False], out[True]
+    assert np.linalg.norm(g0b - g0f) / np.linalg.norm(g0f) < 0.05            # measured 0.02
+    assert np.linalg.norm(aggb - aggf) / np.linalg.norm(aggf) < 0.30         # picks diverge -> different zeroed cells
+    overlap = [len(set(pf[b, :10]) & set(pb[b, :10])) for b in range(3)]
+    assert min(overlap) >= 8, overlap                                        # iteration 0: at most 2 of 10 picks move
+    same = sum(set(pf[b, :10]) == set(pb[b, :10]) for b in range(3))
+    assert same >= 1
 
 
 def test_gradcam_768_geometry_vs_oracle():

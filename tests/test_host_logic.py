@@ -127,3 +127,33 @@ def test_world_size_2_sharding_reduce_gather_over_gloo(tmp_path):
     assert res["hist_sum"] == 12                         # 11 images padded to 12 (one duplicate), like the reference sampler
     assert sorted(res["gathered"][0] + res["gathered"][1]) == sorted(host.shard_indices(11, 0, 2) + host.shard_indices(11, 1, 2))
     assert res["bcast"] == [1.0] * 5
+
+
+def _bench(*args, timeout=300):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                          timeout=timeout, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+
+
+def test_bench_launches_its_own_ranks_dry_run_gloo():
+    """`python bench.py --gpus 2` (no torchrun) starts two rank processes itself; the dry run drives the same
+    rendezvous, weight broadcast, histogram all-reduce and label gather on CPU tensors over gloo."""
+    out = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "2")
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["n_ranks"] == 2 and res["gathered_ranks"] == [0, 1]
+    assert res["hist_total"] == 2 * 35 and res["images_per_rank"] == 70
+
+
+def test_bench_launcher_propagates_a_failed_rank():
+    out = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--dry-run-fail-rank", "1", timeout=600)
+    assert out.returncode != 0
+
+
+def test_bench_under_torchrun_is_a_rank_not_a_launcher(tmp_path):
+    port = 29500 + (os.getpid() + 7) % 2000
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--backend", "gloo", "--dry-run"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_ranks"] == 2

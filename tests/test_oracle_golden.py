@@ -224,3 +224,97 @@ def test_preprocess_tables_host_equals_oracle():
             tab, ks = hip.resample_table(n, S, filt)
             b, kk = PP.resample_coeffs(n, S, filt)
             assert ks == kk.shape[1] and np.array_equal(tab[:, :2], b) and np.array_equal(tab[:, 2:], kk), (filt, n, S)
+
+
+# ------------------------------------------------------------------------------------------ COCO driver
+
+def test_gpt_parse_coco(golden_dir):
+    """Load_predicted_classes of the COCO driver (category id -> position in cats) on sampled shipped strings:
+    oracle and product host parser against the reference's outputs."""
+    from pnp_ovss import host
+    data = json.load(open(os.path.join(golden_dir, "gpt_parse_coco.json")))
+    n = 0
+    for dt, d in data.items():
+        cats = d["cats"]
+        nms = host.coco_class_names(cats)
+        for k, case in d["cases"].items():
+            for fn in (OP.parse_gpt_classes_coco, host.parse_gpt_classes_coco):
+                if "error" in case:
+                    with pytest.raises(Exception):
+                        fn(case["raw"], cats, nms, dt)
+                    continue
+                best, names, cap = fn(case["raw"], cats, nms, dt)
+                assert best == case["best_class_idx"] and names == case["classes"] and cap == case["caption"], (dt, k)
+            n += 1
+    assert n > 100
+
+
+def coco_case(g):
+    """Inputs of a pipeline_coco_*.npz fixture, rebuilt from its seeds (shared with the GPU test)."""
+    from pnp_ovss import host
+    cfg = _cfg(g)
+    data_type = str(g["data_type"])
+    cats = json.loads(str(g["cats"]))
+    nms = host.coco_class_names(cats)
+    class_ids = [c["id"] for c in cats]
+    B = 3
+    _, imgs = synth.synth_images(B, cfg.img_size, seed=int(g["image_seed"]))
+    sizes = [tuple(int(v) for v in s) for s in g["sizes"]]
+    rng = np.random.default_rng(int(g["org_seed"]))
+    org = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
+    gts = [rng.integers(0, int(g["n_class"]), size=(h, w)).astype(np.float32) for h, w in sizes]
+    gpt = json.loads(str(g["gpt"]))
+    tok = SynthTokenizer(cfg.vocab)
+    best, caps = [], []
+    for k in [str(int(s)).rjust(12, "0") for s in g["img_ids"]]:
+        b, names, cap = host.parse_gpt_classes_coco(gpt[k], cats, nms, data_type)
+        best.append(b)
+        caps.append(cap)
+    enc = tok(caps, padding="max_length", max_length=500)
+    ids, mask = enc.input_ids.numpy(), enc.attention_mask.numpy()
+    pieces = [[tok.decode([t]) for t in ids[i][4:int(mask[i].sum()) - 1]] for i in range(B)]
+    return dict(cfg=cfg, data_type=data_type, cats=cats, class_ids=class_ids, imgs=imgs, sizes=sizes, org=org, gts=gts,
+                best=best, caps=caps, ids=ids, mask=mask, pieces=pieces, tok=tok)
+
+
+@pytest.mark.parametrize("fname", ["pipeline_coco_object.npz", "pipeline_coco_stuff.npz"])
+def test_pipeline_coco_end_to_end(golden_dir, fname):
+    """The COCO driver's save_img_union_attention (PnP_OVSS_0514_updated_segmentation_coco.py:338-642) restated:
+    1-drop branch only for drop_iter < 3, Scale_0_1 on both branches, coco background rule, cats[..]['id'] remap,
+    91 / 183-class histogram -- against the reference run (stage-wise bit-exact, end to end up to float ties)."""
+    g = _load(golden_dir, fname)
+    c = coco_case(g)
+    cfg, B, data_type = c["cfg"], 3, c["data_type"]
+    W = synth.synth_state_dict(cfg, int(g["weight_seed"]))
+    n_class = int(g["n_class"])
+    assert any(len(b) < 3 for b in c["best"]) and any(len(b) >= 3 for b in c["best"])      # both background rules
+    for di, mode in ((4, "blur"), (4, None), (2, "blur")):
+        l1, ln, aux = OP.segment_batch(W, cfg, c["imgs"], c["ids"], c["mask"], c["pieces"], c["best"], c["org"], c["sizes"],
+                                       data_type=data_type, drop_iter=di, mode=mode, class_ids=c["class_ids"])
+        tag = f"d{di}_{mode or 'none'}"
+        assert (l1 is None) == (di >= 3)
+        for name, labs, key in (("1drop", l1, "1"), ("ndrop", ln, "n")):
+            if labs is None:
+                assert f"hist_{name}_{tag}" not in g.files
+                continue
+            ref_labs = []
+            for i in range(B):
+                ref_lab = g[f"labels_{name}_{tag}_{i}"].astype(np.float32)
+                ref_labs.append(ref_lab)
+                bg = OP.has_background(data_type, len(c["best"][i]))
+                pre = aux["pre"][key][i]
+                if mode:
+                    ref_pre = g[f"prepost_{name}_{tag}_{i}"]
+                    assert ref_pre.shape[0] == len(c["best"][i]) + int(bg)
+                    np.testing.assert_allclose(pre, ref_pre, rtol=0, atol=2e-5)
+                    stage = OP.remap_labels(OP.postprocess(mode, ref_pre, c["org"][i], c["sizes"][i]), c["best"][i], bg,
+                                            c["class_ids"])
+                    np.testing.assert_array_equal(stage, ref_lab)
+                    pre = np.stack([OP.blurring(pre[ch], c["sizes"][i]) for ch in range(pre.shape[0])])
+                srt = np.sort(pre, axis=0)
+                tie = (srt[-1] - srt[-2]) <= 1e-4 * np.abs(srt[-1]) if pre.shape[0] > 1 else np.zeros(c["sizes"][i], bool)
+                bad = (labs[i] != ref_lab) & ~tie
+                assert bad.sum() == 0, (tag, name, i, int(bad.sum()))
+            # the saved .npy confusion matrix = scores() over the reference's own label maps, n_class 91 / 183
+            _, hist = OP.scores(c["gts"], ref_labs, n_class)
+            np.testing.assert_array_equal(hist, g[f"hist_{name}_{tag}"])

@@ -1,0 +1,107 @@
+"""Which arithmetic decides the salience picks?    BLIP-ITM-large, 336^2, B images, 20-class prompt.
+
+  f32      : exact-fp32 MFMA everywhere (the parity mode)
+  bf16     : bf16 operands / fp32 accumulate everywhere (the throughput mode)
+  vit16    : ViT in bf16, then cross K/V projections + text stack + backward in fp32 on those image_embeds
+  txt16    : ViT in fp32, then cross K/V projections + text stack + backward in bf16
+
+Reports, against f32: relative error of image_embeds, of the selected GradCAM map, equality of the top-10 patch sets of
+iteration 0 per image, and for the full 4-iteration drop loop the pick-set equality per iteration plus the label
+disagreement after blur+CRF.   python tools/precision_probe.py [B]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "pnp-ovss_amd")):
+    sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+from pnp_ovss import config as C, synth
+from pnp_ovss.hip import Engine
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+IMG, NCLS, HEAD, LAYER = 336, 20, 9, 7
+cfg = C.blip_itm_large(IMG)
+W = synth.synth_state_dict(cfg, 0)
+rgb, imgs = synth.synth_images(B, IMG, seed=1234, noise=4)
+ids, mask = synth.synth_tokens(cfg, [NCLS] * B, seed=1234)
+L = int(mask.sum(1).max())
+d_img = torch.from_numpy(imgs).cuda()
+d_ids, d_mask = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+N, D = cfg.n_img_tokens, cfg.vit_dim
+
+eng = {}
+for name, bf in (("f32", False), ("bf16", True)):
+    e = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=LAYER, bf16=bf)
+    e.load_state_dict(W)
+    e.post_reserve(B, B * IMG * IMG, IMG * IMG, NCLS + 1, 0)
+    eng[name] = e
+
+
+def top10(G):
+    sal = G[:, 3:-1].sum(1).reshape(G.shape[0], -1)
+    return [set(np.argsort(s, kind="stable")[-10:].tolist()) for s in sal.cpu().numpy()]
+
+
+def rest(e, B):
+    e.text_forward(d_ids, d_mask, L)
+    e.xattn_grad(B, L)
+    return e.gradcam_gather(d_mask, L, HEAD)
+
+
+def inject(dst, emb32):
+    """overwrite dst's image_embeds (fp32 copy + compute-type copy) and re-project the cross K/V"""
+    p32, _ = dst.buffer_ptr("image_embeds")
+    pt, _ = dst.buffer_ptr("image_embeds_t")
+    n = B * N * D
+    torch.as_tensor(dst.buffer("image_embeds"))[:n].copy_(emb32.reshape(-1))
+    assert dst.lib.pnp_op_cast(1 if dst.bf16 else 0, p32, pt, n, None) == 0
+    dst.cross_kv(B)
+
+
+out = {}
+G = {}
+emb = {}
+for name, e in eng.items():
+    G[name], _ = e.compute_gradcam(d_img, d_ids, d_mask, L, HEAD)
+    torch.cuda.synchronize()
+    emb[name] = e.buffer("image_embeds")[: B * N * D].clone()
+inject(eng["f32"], emb["bf16"]);  G["vit16"] = rest(eng["f32"], B)
+inject(eng["bf16"], emb["f32"]);  G["txt16"] = rest(eng["bf16"], B)
+torch.cuda.synchronize()
+ref = G["f32"]
+t_ref = top10(ref)
+out["image_embeds_rel_err_bf16"] = float((emb["bf16"] - emb["f32"]).norm() / emb["f32"].norm())
+for k in ("bf16", "vit16", "txt16"):
+    t = top10(G[k])
+    out[k] = {"map_rel_err": float((G[k] - ref).norm() / ref.norm()),
+              "map_max_abs_err_over_max": float((G[k] - ref).abs().max() / ref.abs().max()),
+              "iter0_top10_sets_equal": int(sum(a == b for a, b in zip(t, t_ref))), "of": B,
+              "iter0_top10_mean_overlap": float(np.mean([len(a & b) for a, b in zip(t, t_ref)]))}
+
+# full drop loop + both post-process branches
+sizes = [(IMG, IMG)] * B
+plans = [[([i], 1) for i in range(NCLS)]] * B
+luts = [list(range(NCLS + 1))] * B
+d_rgb = torch.from_numpy(rgb.reshape(-1)).cuda()
+res = {}
+for name, e in eng.items():
+    g0, agg, picks, _ = e.drop_loop(d_img, d_ids, d_mask, L, HEAD, 4)
+    e.post_prepare(sizes, plans, luts, [True] * B, rgb=d_rgb, gt=None, want_crf=True)
+    l1, ln = e.postprocess_pair(g0, agg, 0.15, 21)
+    torch.cuda.synchronize()
+    res[name] = (picks.cpu().numpy(), l1.cpu().numpy(), ln.cpu().numpy(), g0.cpu().numpy(), agg.cpu().numpy())
+p32, p16 = res["f32"][0], res["bf16"][0]
+out["drop_loop"] = {"pick_sets_equal_per_iter": [int(sum(set(p32[b, : (it + 1) * 10]) == set(p16[b, : (it + 1) * 10]) for b in range(B)))
+                                                 for it in range(4)], "of": B,
+                    "labels_1drop_disagree_frac": float((res["f32"][1] != res["bf16"][1]).mean()),
+                    "labels_ndrop_disagree_frac": float((res["f32"][2] != res["bf16"][2]).mean()),
+                    "g0_rel_err": float(np.linalg.norm(res["f32"][3] - res["bf16"][3]) / np.linalg.norm(res["f32"][3])),
+                    "agg_rel_err": float(np.linalg.norm(res["f32"][4] - res["bf16"][4]) / np.linalg.norm(res["f32"][4]))}
+print(json.dumps(out, indent=1))
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "precision_probe.json"), "w"), indent=1)
