@@ -14,6 +14,8 @@ Restates, citing the reference files under `/root/reference/Files to replace for
   * gradcam = P[...,1:] * relu(dP[...,1:]) * mask, clamp, drop [ENC] row
                                           B/blip_image_text_matching.py:411-435
 
+  * checkpoint pos-embed re-tiling        B/base_model.py:44-73 (interpolate_pos_embed: bicubic, align_corners=False)
+
 Pinned against golden vectors generated from the reference itself (tests/golden/make_golden.py).
 """
 import math
@@ -239,3 +241,39 @@ def compute_gradcam(W, cfg, imgs, ids500, mask500, layers=None):
         out[l] = gradcam_from(caches[l]["Pc"], dps[l], m, cfg.grid)
         raw[l] = (caches[l]["Pc"], dps[l])
     return out, logits, raw
+
+
+# ------------------------------------------------------------------------------------- weights in
+
+def _cubic_taps(in_size, out_size):
+    """torch upsample_bicubic2d, align_corners=False: source x = (dst + 0.5) * in/out - 0.5 (not clamped), taps at
+    floor(x) - 1 .. floor(x) + 2 clamped to the border, cubic-convolution weights with A = -0.75."""
+    A = -0.75
+    scale = in_size / out_size
+    x = (np.arange(out_size) + 0.5) * scale - 0.5
+    ix = np.floor(x).astype(np.int64)
+    t = (x - ix).astype(np.float64)
+
+    def c1(v):
+        return ((A + 2) * v - (A + 3)) * v * v + 1
+
+    def c2(v):
+        return ((A * v - 5 * A) * v + 8 * A) * v - 4 * A
+    w = np.stack([c2(t + 1), c1(t), c1(1 - t), c2(2 - t)], axis=1)
+    idx = np.clip(ix[:, None] + np.arange(-1, 3)[None, :], 0, in_size - 1)
+    return idx, w
+
+
+def interpolate_pos_embed(pos, new_grid):
+    """B/base_model.py:44-73: checkpoint pos_embed (1, 1 + g*g, D) -> (1, 1 + new_grid^2, D); the class token is kept,
+    the g x g grid is resized bicubically (torch F.interpolate(mode="bicubic", align_corners=False))."""
+    pos = np.asarray(pos, dtype=F32)
+    D = pos.shape[-1]
+    g = int(round((pos.shape[-2] - 1) ** 0.5))
+    if g == new_grid:
+        return pos
+    grid = pos[0, 1:].reshape(g, g, D).astype(np.float64)
+    iy, wy = _cubic_taps(g, new_grid)
+    tmp = np.einsum("oi,oixd->oxd", wy, grid[iy])             # rows
+    out = np.einsum("pj,opjd->opd", wy, tmp[:, iy])           # columns (square: same taps)
+    return np.concatenate([pos[:, :1], out.reshape(1, new_grid * new_grid, D).astype(F32)], axis=1)

@@ -187,6 +187,29 @@ def _resize_pos_embed(pos, n_new_grid):
     return torch.cat((extra, grid), dim=1)
 
 
+def merge_checkpoint(cfg, ckpt_state, init_state):
+    """BaseModel.load_checkpoint (base_model.py:86-125) as a pure host function: `ckpt_state` (the checkpoint's
+    "model" dict) over `init_state` (the module's values before loading).  The pos_embed grid is re-tiled to cfg.grid
+    (:108-110), keys whose shape differs from the model's are dropped (:116-119), everything else overwrites
+    (strict=False: keys the path does not have are ignored).  Returns (state, dropped, missing): `missing` = path
+    tensors the checkpoint did not provide (they keep their init value, as in the reference)."""
+    shapes = synth.param_shapes(cfg)
+    ck = dict(ckpt_state)
+    if "visual_encoder.pos_embed" in ck:
+        ck["visual_encoder.pos_embed"] = _resize_pos_embed(ck["visual_encoder.pos_embed"], cfg.grid)
+    state, dropped, missing = {}, [], []
+    for k, shp in shapes.items():
+        if k in ck and tuple(ck[k].shape) == tuple(shp):
+            state[k] = ck[k]
+        else:
+            if k in ck:
+                dropped.append(k)
+            else:
+                missing.append(k)
+            state[k] = init_state[k]
+    return state, dropped, missing
+
+
 def build_model(model_type="large", img_size=336, device=0, max_batch=35, max_text_len=64, stash_layer=7, bf16=True,
                 checkpoint=None, vocab=None, seed=0, cfg=None):
     """from_config + load_checkpoint (blip_image_text_matching.py:297-314, base_model.py:86-125)."""
@@ -198,16 +221,18 @@ def build_model(model_type="large", img_size=336, device=0, max_batch=35, max_te
     vocab = vocab or os.environ.get("PNP_OVSS_VOCAB")
     dev = device if isinstance(device, int) else (torch.device(device).index or 0)
     eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len, stash_layer=stash_layer, bf16=bf16, device=dev)
+    init = synth.synth_state_dict(cfg, seed)                      # stands in for the module's initialisation
     if checkpoint:
         sd = torch.load(checkpoint, map_location="cpu")
         sd = sd["model"] if "model" in sd else sd
-        sd["visual_encoder.pos_embed"] = _resize_pos_embed(sd["visual_encoder.pos_embed"], cfg.grid)
-        shapes = synth.param_shapes(cfg)
-        sd = {k: v for k, v in sd.items() if k in shapes and tuple(v.shape) == tuple(shapes[k])}   # :116-119
-        eng.load_state_dict(sd)
+        state, dropped, missing = merge_checkpoint(cfg, sd, init)
+        if dropped or missing:
+            warnings.warn(f"checkpoint {checkpoint}: dropped (shape mismatch) {dropped}, not provided {missing}: "
+                          f"those tensors keep their initial values, like load_state_dict(strict=False)")
+        eng.load_state_dict(state)
     else:
         warnings.warn("no BLIP checkpoint given (PNP_OVSS_CHECKPOINT): using seeded synthetic weights")
-        eng.load_state_dict(synth.synth_state_dict(cfg, seed))
+        eng.load_state_dict(init)
     tok = WordPieceTokenizer(vocab) if vocab else SynthTokenizer(cfg.vocab)
     return BlipITM(cfg, eng, tok)
 

@@ -104,6 +104,17 @@ def synth_state_dict(cfg: ModelCfg, seed: int = 0, names=None) -> "OrderedDict[s
     return out
 
 
+def synth_checkpoint(cfg_model: ModelCfg, cfg_ckpt: ModelCfg, seed: int = 7) -> "OrderedDict[str, np.ndarray]":
+    """A synthetic BLIP checkpoint state dict fine-tuned at another resolution (pos_embed of cfg_ckpt's grid, like the
+    384-px flickr checkpoint of blip_itm_large.yaml:10), with the extra heads a real one carries and ONE
+    shape-mismatched key (itm_head.bias) that load_checkpoint must drop (base_model.py:116-119)."""
+    sd = synth_state_dict(cfg_ckpt, seed)
+    sd["vision_proj.weight"] = np.zeros((8, cfg_model.vit_dim), dtype=np.float32)
+    sd["text_proj.weight"] = np.zeros((8, cfg_model.txt_hidden), dtype=np.float32)
+    sd["itm_head.bias"] = np.zeros((3,), dtype=np.float32)
+    return sd
+
+
 # ----------------------------------------------------------------------------- inputs
 
 CLIP_MEAN = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)   # Dataset.py:434-443

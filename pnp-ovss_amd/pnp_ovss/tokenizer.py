@@ -94,54 +94,98 @@ class SynthTokenizer(_Base):
         return " ".join(self._id2piece.get(int(i), "[UNK]") for i in ids)
 
 
+def _is_punct(ch):
+    cp = ord(ch)
+    if 33 <= cp <= 47 or 58 <= cp <= 64 or 91 <= cp <= 96 or 123 <= cp <= 126:
+        return True
+    import unicodedata
+    return unicodedata.category(ch).startswith("P")
+
+
+def _is_cjk(cp):
+    return (0x4E00 <= cp <= 0x9FFF or 0x3400 <= cp <= 0x4DBF or 0x20000 <= cp <= 0x2A6DF or 0x2A700 <= cp <= 0x2B73F
+            or 0x2B740 <= cp <= 0x2B81F or 0x2B820 <= cp <= 0x2CEAF or 0xF900 <= cp <= 0xFAFF or 0x2F800 <= cp <= 0x2FA1F)
+
+
 class WordPieceTokenizer(_Base):
-    """Greedy longest-match-first word-piece (BERT) over a vocab.txt; lower-cases and splits
-    punctuation like BertTokenizer's BasicTokenizer for the ASCII class names used here."""
+    """BertTokenizer("bert-base-uncased") as LAVIS' BlipBase.init_tokenizer sets it up (blip_image_text_matching.py:42):
+    BERT basic tokenisation (clean control characters, whitespace split, lower-case, NFD accent stripping, every
+    punctuation character its own token, CJK characters spaced) followed by greedy longest-match-first word-piece
+    (words over 100 characters or without a decomposition -> [UNK]) over a vocab.txt, plus the two added tokens
+    "[DEC]" (bos) and "[ENC]" after the base entries.  Pinned against HF BertTokenizer on
+    tests/golden/tokenizer_cases.json."""
+    max_chars_per_word = 100
 
     def __init__(self, vocab_path):
         with open(vocab_path, encoding="utf-8") as f:
             toks = [l.rstrip("\n") for l in f]
+        while toks and toks[-1] == "":
+            toks.pop()
         toks += ["[DEC]", "[ENC]"]
         self._piece2id = {t: i for i, t in enumerate(toks)}
         self._id2piece = toks
         self.vocab_size = len(toks)
         self.enc_token_id = self._piece2id["[ENC]"]
         self.unk_token_id = self._piece2id.get("[UNK]", 100)
+        self.pad_token_id = self._piece2id.get("[PAD]", 0)
+        self.cls_token_id = self._piece2id.get("[CLS]", 101)
+        self.sep_token_id = self._piece2id.get("[SEP]", 102)
 
-    def _pieces(self, word):
-        words, cur = [], ""
-        for ch in word:
-            if ch.isalnum():
-                cur += ch
-            else:
-                if cur:
-                    words.append(cur)
-                    cur = ""
-                words.append(ch)
-        if cur:
-            words.append(cur)
+    def _basic(self, text):
+        import unicodedata
         out = []
-        for w in words:
-            start, sub = 0, []
-            bad = False
-            while start < len(w):
-                end = len(w)
-                piece = None
-                while start < end:
-                    s = w[start:end]
-                    if start > 0:
-                        s = "##" + s
-                    if s in self._piece2id:
-                        piece = s
-                        break
-                    end -= 1
-                if piece is None:
-                    bad = True
-                    break
-                sub.append(piece)
-                start = end
-            out.extend(["[UNK]"] if bad else sub)
+        for ch in text:                                   # clean_text + CJK spacing
+            cp = ord(ch)
+            if cp == 0 or cp == 0xFFFD or (ch not in "\t\n\r" and unicodedata.category(ch) in ("Cc", "Cf")):
+                continue
+            if _is_cjk(cp):
+                out.append(" " + ch + " ")
+            elif ch in " \t\n\r" or unicodedata.category(ch) == "Zs":
+                out.append(" ")
+            else:
+                out.append(ch)
+        words = []
+        for tok in "".join(out).split():
+            tok = "".join(c for c in unicodedata.normalize("NFD", tok.lower()) if unicodedata.category(c) != "Mn")
+            cur = ""
+            for ch in tok:                                # punctuation splits
+                if _is_punct(ch):
+                    if cur:
+                        words.append(cur)
+                        cur = ""
+                    words.append(ch)
+                else:
+                    cur += ch
+            if cur:
+                words.append(cur)
+        return words
+
+    def tokenize(self, text):
+        out = []
+        for w in self._basic(text):
+            out.extend(self._pieces(w))
         return out
+
+    def _pieces(self, w):
+        if len(w) > self.max_chars_per_word:
+            return ["[UNK]"]
+        start, sub = 0, []
+        while start < len(w):
+            end = len(w)
+            piece = None
+            while start < end:
+                s = w[start:end]
+                if start > 0:
+                    s = "##" + s
+                if s in self._piece2id:
+                    piece = s
+                    break
+                end -= 1
+            if piece is None:
+                return ["[UNK]"]
+            sub.append(piece)
+            start = end
+        return sub
 
     def _piece_id(self, piece):
         return self._piece2id.get(piece, self.unk_token_id)

@@ -409,6 +409,120 @@ def gen_gpt_parse_coco():
     print("gpt_parse_coco:", {k: (len(v["cases"]), sum("error" in c for c in v["cases"].values())) for k, v in res.items()})
 
 
+def _ref_base_model_functions():
+    """interpolate_pos_embed and BaseModel.load_checkpoint exec'd from the reference's base_model.py (the module itself
+    needs omegaconf / LAVIS dist utils, the two functions need only torch / os / logging)."""
+    import ast as _ast
+    import logging
+    path = RL.REF_B + "base_model.py"
+    tree = _ast.parse(open(path).read())
+    ns = dict(torch=torch, os=os, logging=logging, is_url=lambda p: False, download_cached_file=None)
+    for node in tree.body:
+        if isinstance(node, _ast.FunctionDef) and node.name == "interpolate_pos_embed":
+            exec(compile(_ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+        if isinstance(node, _ast.ClassDef) and node.name == "BaseModel":
+            for sub in node.body:
+                if isinstance(sub, _ast.FunctionDef) and sub.name == "load_checkpoint":
+                    exec(compile(_ast.Module(body=[sub], type_ignores=[]), path, "exec"), ns)
+    return ns["interpolate_pos_embed"], ns["load_checkpoint"]
+
+
+def gen_pos_embed():
+    """interpolate_pos_embed (base_model.py:44-73) for the two re-tilings the configs need: the 384-px flickr
+    checkpoint's 24 x 24 grid -> 21 x 21 (336 px) and -> 48 x 48 (768 px, BASELINE config 5)."""
+    interp, _ = _ref_base_model_functions()
+    rng = np.random.default_rng(21)
+    D = 24
+    pos = rng.standard_normal((1, 1 + 24 * 24, D)).astype(np.float32)
+    out = {"pos_24": pos}
+    for g in (21, 48, 24):
+        class V:
+            pass
+        v = V()
+        v.patch_embed = V()
+        v.patch_embed.num_patches = g * g
+        v.pos_embed = torch.zeros(1, 1 + g * g, D)
+        out[f"pos_{g}_from_24"] = interp(torch.from_numpy(pos.copy()), v).numpy()
+    np.savez_compressed(os.path.join(HERE, "pos_embed_cases.npz"), **out)
+    print("pos_embed_cases:", {k: v.shape for k, v in out.items()})
+
+
+def gen_checkpoint_small():
+    """BaseModel.load_checkpoint (base_model.py:86-125) on the reference model: seeded init (seed 3) -> load a synthetic
+    checkpoint saved at grid 8 (128 px) into the 64-px model -> compute_gradcam_ensemble.  Golden: resized pos_embed,
+    the surviving itm_head.bias (mismatched key dropped -> init value kept), maps [7][9], logits."""
+    _, load_checkpoint = _ref_base_model_functions()
+    cfg = C.blip_itm_small(64)
+    cfg_ck = C.blip_itm_small(128)
+    m, itm, tok = _model(cfg, seed=3)
+    ck = synth.synth_checkpoint(cfg, cfg_ck, 7)
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "ckpt.pth")
+    torch.save({"model": {k: torch.from_numpy(v.copy()) for k, v in ck.items()}}, path)
+    msg = load_checkpoint(m, path)
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=5)
+    caps = ["A picture of cat aeroplane dog sheep boat", "A picture of bus tvmonitor"]
+    tok500 = tok(caps, padding="max_length", max_length=500, return_tensors="pt")
+    args = argparse.Namespace(img_size=cfg.img_size)
+    g, _, out = itm.compute_gradcam_ensemble(args, m, torch.from_numpy(imgs), caps, tok500)
+    sd = m.state_dict()
+    np.savez_compressed(os.path.join(HERE, "checkpoint_small.npz"), cfg=json.dumps(cfg.as_dict()),
+                        cfg_ckpt=json.dumps(cfg_ck.as_dict()), init_seed=3, ckpt_seed=7, image_seed=5, captions=np.array(caps),
+                        pos_embed=sd["visual_encoder.pos_embed"].numpy(), itm_head_bias=sd["itm_head.bias"].numpy(),
+                        missing=np.array(sorted(msg.missing_keys)), unexpected=np.array(sorted(msg.unexpected_keys)),
+                        map_7_9=g[7][9].numpy(), logits=out.detach().numpy())
+    print("checkpoint_small: missing", msg.missing_keys, "unexpected", msg.unexpected_keys)
+
+
+def gen_tokenizer():
+    """LAVIS BlipBase.init_tokenizer (blip_image_text_matching.py:42): HF BertTokenizer +
+    add_special_tokens bos "[DEC]" + additional "[ENC]", run on a small committed vocabulary laid out like
+    bert-base-uncased's (specials at 0 / 100-103).  Golden: ids / masks for the two call forms of the drivers
+    (padding="max_length" PnP.py:317 and padding="longest", truncation blip_image_text_matching.py:230-236) and the
+    per-id decode strings the merge walk reads (PnP.py:812-819)."""
+    from transformers import BertTokenizer
+    from pnp_ovss import datasets as DS
+    words = ("a picture of aero ##plane bi ##cycle bird boat bottle bus car cat chair cow table dog horse motor ##bike person "
+             "potted ##plant sheep sofa train tv ##mon ##itor wall sky floor tree ceiling road bed window ##pane grass cabinet "
+             "side ##walk ground door mountain plant curtain water painting shelf house sea mirror rug field arm ##chair seat "
+             "fence desk rock ward ##robe lamp bath ##tub rail ##ing cushion base box pillar sign ##board chest ##of ##draw ##ers "
+             "traffic ##light fire ##hy ##dran ##t stop parking meter bench ele ##phant bear zebra gi ##raf ##fe back ##pack "
+             "umbrella hand ##bag tie suit ##case fr ##is ##bee ski ##s snow sports ##ball kite base ##ball bat glove skate "
+             "surf tennis racket wine ##glass cup fork knife spoon bowl banana apple sand ##wich orange bro ##cco ##li carrot "
+             "hot ##dog pizza don ##ut cake couch dining toilet laptop mouse remote key cell ##phone micro ##wave oven toast "
+             "##er sink re ##fr ##iger ##ator book clock vase sci ##sso ##rs teddy hair ##dr ##ier tooth ##brush it").split()
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(1, 100)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    vocab += list("abcdefghijklmnopqrstuvwxyz") + ["##" + ch for ch in "abcdefghijklmnopqrstuvwxyz"] + list("0123456789")
+    vocab += list(",.-'!?()/")
+    for w in words:
+        if w not in vocab:
+            vocab.append(w)
+    open(os.path.join(HERE, "tiny_vocab.txt"), "w").write("\n".join(vocab) + "\n")
+    t = BertTokenizer(vocab={w: i for i, w in enumerate(vocab)})
+    t.add_special_tokens({"bos_token": "[DEC]"})
+    t.add_special_tokens({"additional_special_tokens": ["[ENC]"]})
+    coco = ["".join("".join(n.split(" ")).split("-")) for n in list(COCO_THINGS.values()) + list(COCO_STUFF.values())]
+    ade = ["".join(n.split(" ")) for n in DS.ADE_NAMES]
+    caps = ["A picture of " + " ".join(VOC_CATS.values()),
+            "A picture of " + " ".join(DS.PSC_NAMES[:30]), "A picture of " + " ".join(DS.PSC_NAMES[30:]),
+            "A picture of " + " ".join(ade[:40]), "A picture of " + " ".join(ade[100:150]),
+            "A picture of " + " ".join(coco[:45]), "A picture of " + " ".join(coco[80:130]),
+            "A picture of cat", "A picture of pottedplant tvmonitor",
+            "A Picture of  Dog-x, it's caf\u00e9 time!  (sofa/tv) 12 stra\u00dfe", "", "a " + "x" * 120 + " b"]
+    out = {"captions": caps, "vocab_size": len(t), "enc_token_id": t.convert_tokens_to_ids("[ENC]"),
+           "dec_token_id": t.convert_tokens_to_ids("[DEC]")}
+    e = t(caps, padding="max_length", max_length=500, return_tensors="pt")
+    out["max_length_500"] = {"input_ids": [r[: int(m.sum())].tolist() for r, m in zip(e.input_ids, e.attention_mask)]}
+    e2 = t(caps, padding="longest", truncation=True, max_length=500, return_tensors="pt")
+    out["longest"] = {"shape": list(e2.input_ids.shape), "input_ids": e2.input_ids.tolist(), "attention_mask": e2.attention_mask.tolist()}
+    e3 = t(caps[:3], padding="longest", truncation=True, max_length=16, return_tensors="pt")
+    out["truncate_16"] = {"input_ids": e3.input_ids.tolist(), "attention_mask": e3.attention_mask.tolist()}
+    ids = sorted({i for r in out["max_length_500"]["input_ids"] for i in r} | {0, 100, out["enc_token_id"]})
+    out["decode"] = {str(i): t.decode([i]) for i in ids}
+    json.dump(out, open(os.path.join(HERE, "tokenizer_cases.json"), "w"), indent=0)
+    print("tokenizer_cases:", len(caps), "captions, vocab", len(t), "longest", out["longest"]["shape"])
+
+
 def gen_gpt_parse():
     ns = RL.load_driver_functions(["Load_predicted_classes"], dict(json=json))
     res = {}
@@ -511,7 +625,8 @@ def gen_preprocess_cases():
 GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, droploop_small=gen_droploop_small,
             merge_tokens=gen_merge_tokens, pipeline_voc=gen_pipeline_voc, pipeline_psc=gen_pipeline_psc,
             pipeline_coco_object=gen_pipeline_coco_object, pipeline_coco_stuff=gen_pipeline_coco_stuff,
-            gpt_parse_coco=gen_gpt_parse_coco, gpt_parse=gen_gpt_parse,
+            gpt_parse_coco=gen_gpt_parse_coco, gpt_parse=gen_gpt_parse, tokenizer=gen_tokenizer,
+            pos_embed=gen_pos_embed, checkpoint_small=gen_checkpoint_small,
             blur_cases=gen_blur_cases, hist_cases=gen_hist_cases, preprocess_cases=gen_preprocess_cases)
 
 if __name__ == "__main__":

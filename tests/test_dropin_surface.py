@@ -173,3 +173,28 @@ def test_coco_dataset_layout_and_rules(tmp_path):
     best, names, cap = ds.predicted_classes(139)
     assert best == [2, 1] and names == ["trafficlight", "car"] and cap == "A picture of trafficlight car"   # id 77: not a category here
     assert host.remap_lut(best, True, 3, ds.class_ids) == [0, 10, 3]
+
+
+def test_build_model_from_checkpoint_matches_reference_load_checkpoint(tmp_path, golden_dir):
+    """a-16: `build_model(checkpoint=...)` (torch.load -> pos-embed re-tile -> drop mismatched keys -> engine) against the
+    reference model after its own BaseModel.load_checkpoint of the same synthetic .pth (golden checkpoint_small.npz)."""
+    import argparse as ap
+    from pnp_ovss import config as C, synth
+    from pnp_ovss.model import build_model
+    from lavis.models.blip_models.blip_image_text_matching import compute_gradcam_ensemble
+    g = np.load(os.path.join(golden_dir, "checkpoint_small.npz"))
+    cfg = C.ModelCfg(**json.loads(str(g["cfg"])))
+    cfg_ck = C.ModelCfg(**json.loads(str(g["cfg_ckpt"])))
+    ck = synth.synth_checkpoint(cfg, cfg_ck, int(g["ckpt_seed"]))
+    path = str(tmp_path / "ckpt.pth")
+    torch.save({"model": {k: torch.from_numpy(v.copy()) for k, v in ck.items()}}, path)
+    with pytest.warns(UserWarning, match="itm_head.bias"):
+        model = build_model(cfg=cfg, max_batch=2, max_text_len=32, stash_layer=7, bf16=False, checkpoint=path,
+                            seed=int(g["init_seed"]))
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=int(g["image_seed"]))
+    caps = [str(c) for c in g["captions"]]
+    tok500 = model.module.tokenizer(caps, padding="max_length", max_length=500, return_tensors="pt")
+    blocks, _, logits = compute_gradcam_ensemble(ap.Namespace(img_size=cfg.img_size), model.module, torch.from_numpy(imgs), caps, tok500)
+    assert np.abs(blocks[7][9].numpy() - g["map_7_9"]).max() < 1e-4
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=5e-3)
+    model.engine.close()

@@ -592,7 +592,10 @@ def test_end_to_end_coco_driver_vs_reference_run(fname):
     c = coco_case(g)
     cfg, B = c["cfg"], 3
     n_class = int(g["n_class"])
-    e = _engine(cfg, int(g["weight_seed"]), False, max_batch=4, max_text_len=40)
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    e = Engine(cfg, max_batch=4, max_text_len=40, stash_layer=7, bf16=False)     # own engine: the Segmenter reserves its workspace
+    e.load_state_dict(synth.synth_state_dict(cfg, int(g["weight_seed"])))
     model = BlipITM(cfg, e, c["tok"])
     segs = {}
     for di, mode in ((4, "blur"), (4, None), (2, "blur")):
@@ -627,6 +630,7 @@ def test_end_to_end_coco_driver_vs_reference_run(fname):
                 np.testing.assert_array_equal(hist.cpu().numpy().reshape(n_class, n_class), g[f"hist_{name}_{tag}"].astype(np.int64))
             else:
                 assert np.abs(hist.cpu().numpy().reshape(n_class, n_class) - g[f"hist_{name}_{tag}"]).sum() <= 2 * n
+    e.close()
 
 
 def test_bf16_vs_f32_divergence_is_bounded():

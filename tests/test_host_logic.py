@@ -157,3 +157,66 @@ def test_bench_under_torchrun_is_a_rank_not_a_launcher(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_ranks"] == 2
+
+
+def test_wordpiece_tokenizer_matches_hf_bert_tokenizer_golden():
+    """pnp_ovss.tokenizer.WordPieceTokenizer against ids produced by HF BertTokenizer + LAVIS' [DEC] / [ENC] additions
+    on the committed tiny vocabulary (tests/golden/make_golden.py:gen_tokenizer): class-name captions of all five
+    datasets (so ## splits decide the merge plan), punctuation, accents, unknown words, an over-long word, an empty
+    caption; both call forms of the drivers and the per-id decode strings."""
+    from pnp_ovss.tokenizer import WordPieceTokenizer
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "tokenizer_cases.json")))
+    tok = WordPieceTokenizer(os.path.join(ROOT, "tests", "golden", "tiny_vocab.txt"))
+    assert tok.vocab_size == g["vocab_size"] and tok.enc_token_id == g["enc_token_id"]
+    caps = g["captions"]
+    e = tok(caps, padding="max_length", max_length=500, return_tensors="pt")
+    assert e.input_ids.shape == (len(caps), 500)
+    for i, ref in enumerate(g["max_length_500"]["input_ids"]):
+        n = int(e.attention_mask[i].sum())
+        assert e.input_ids[i, :n].tolist() == ref, (i, caps[i])
+        assert int(e.input_ids[i, n:].abs().sum()) == 0
+    e2 = tok(caps, padding="longest", truncation=True, max_length=500, return_tensors="pt")
+    assert list(e2.input_ids.shape) == g["longest"]["shape"]
+    assert e2.input_ids.tolist() == g["longest"]["input_ids"] and e2.attention_mask.tolist() == g["longest"]["attention_mask"]
+    e3 = tok(caps[:3], padding="longest", truncation=True, max_length=16, return_tensors="pt")
+    assert e3.input_ids.tolist() == g["truncate_16"]["input_ids"] and e3.attention_mask.tolist() == g["truncate_16"]["attention_mask"]
+    for i, s in g["decode"].items():
+        assert tok.decode([int(i)]) == s, i
+    # the merge plan the device kernel is fed with follows from those pieces (PnP.py:812-853)
+    pieces = host.caption_pieces(tok, e.input_ids[8].numpy())          # "A picture of pottedplant tvmonitor"
+    assert pieces == ["potted", "##plant", "tv", "##mon", "##itor"]
+    assert host.merge_plan(pieces, 2) == [([0, 1], 2), ([2, 3, 4], 1)]
+
+
+def test_pos_embed_retile_matches_reference_interpolate_pos_embed():
+    """base_model.py:44-73 on the two re-tilings the configs need (24^2 -> 21^2 for 336 px, 24^2 -> 48^2 for 768 px):
+    the product's host function and the oracle's numpy bicubic against the reference's own output."""
+    from pnp_ovss.model import _resize_pos_embed
+    from oracle import blip_itm_np as OM
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pos_embed_cases.npz"))
+    for grid in (21, 48, 24):
+        ref = g[f"pos_{grid}_from_24"]
+        got = _resize_pos_embed(g["pos_24"], grid).numpy()
+        assert got.shape == ref.shape == (1, 1 + grid * grid, 24)
+        np.testing.assert_array_equal(got[:, 0], g["pos_24"][:, 0])          # class token untouched
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(OM.interpolate_pos_embed(g["pos_24"], grid), ref, rtol=0, atol=2e-5)   # float64 taps vs torch float32
+
+
+def test_merge_checkpoint_matches_reference_load_checkpoint():
+    """BaseModel.load_checkpoint semantics (base_model.py:86-125) on a synthetic checkpoint saved at another
+    resolution with one shape-mismatched key: golden = the reference model's state after ITS load_checkpoint."""
+    from pnp_ovss import config as C, synth
+    from pnp_ovss.model import merge_checkpoint
+    g = np.load(os.path.join(ROOT, "tests", "golden", "checkpoint_small.npz"))
+    cfg = C.ModelCfg(**json.loads(str(g["cfg"])))
+    cfg_ck = C.ModelCfg(**json.loads(str(g["cfg_ckpt"])))
+    init = synth.synth_state_dict(cfg, int(g["init_seed"]))
+    ck = synth.synth_checkpoint(cfg, cfg_ck, int(g["ckpt_seed"]))
+    import torch
+    state, dropped, missing = merge_checkpoint(cfg, {k: torch.from_numpy(v) for k, v in ck.items()}, init)
+    assert dropped == ["itm_head.bias"] and missing == []
+    assert "itm_head.bias" in [str(k) for k in g["missing"]]                  # the reference reports it as not loaded too
+    np.testing.assert_allclose(np.asarray(state["visual_encoder.pos_embed"]), g["pos_embed"], rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(np.asarray(state["itm_head.bias"]), g["itm_head_bias"])       # init value kept
+    np.testing.assert_array_equal(np.asarray(state["itm_head.weight"]), ck["itm_head.weight"])  # checkpoint value taken

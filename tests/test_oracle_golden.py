@@ -318,3 +318,50 @@ def test_pipeline_coco_end_to_end(golden_dir, fname):
             # the saved .npy confusion matrix = scores() over the reference's own label maps, n_class 91 / 183
             _, hist = OP.scores(c["gts"], ref_labs, n_class)
             np.testing.assert_array_equal(hist, g[f"hist_{name}_{tag}"])
+
+
+# ------------------------------------------------------------------------------------------ DenseCRF evidence
+
+def _crf_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_crf_golden", os.path.join(os.path.dirname(__file__), "golden", "make_crf_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.crf_cases()
+
+
+def test_crf_lattice_oracle_vs_brute_force_exact_dense_crf():
+    """Independent evidence for oracle/densecrf_ref.c (pydensecrf is not installable here): the same mean-field with
+    every kernel entry evaluated explicitly in float64 (oracle/densecrf_exact.py, N x N) on images up to 40 x 40.
+    The permutohedral lattice only approximates the Gaussian kernels, so the agreement is statistical; measured here:
+    labels agree on 99.4-100 % of the pixels while the CRF moves 7-34 % of the plain-argmax labels (so agreement is
+    not trivial), mean |Q_lattice - Q_exact| <= 4e-3."""
+    from oracle.densecrf_exact import densecrf_exact
+    agree, moved = [], []
+    for rgb, maps in _crf_cases()[:5]:
+        lab_l, q_l, _ = OP.densecrf(rgb, maps, want_q=True)
+        lab_e, q_e = densecrf_exact(rgb, maps)
+        a = float((lab_l == lab_e).mean())
+        agree.append(a)
+        moved.append(float((np.argmax(maps, axis=0) != lab_e).mean()))
+        assert a >= 0.99, a
+        assert np.abs(q_l - q_e).mean() < 0.01
+        np.testing.assert_allclose(q_e.sum(axis=0), 1.0, atol=1e-9)
+    assert min(moved) > 0.05 and np.mean(agree) > 0.995, (agree, moved)
+
+
+def test_crf_oracle_vs_pydensecrf_fixture(golden_dir):
+    """Consumes tests/golden/crf_pydensecrf.npz -- produced by tests/golden/make_crf_golden.py on a machine that has
+    pydensecrf, running the reference's exact call sequence (PnP.py:1063-1073).  Absent here: SKIPPED, and the DenseCRF
+    row stays "parity unpinned" (DESIGN.md 4)."""
+    path = os.path.join(golden_dir, "crf_pydensecrf.npz")
+    if not os.path.exists(path):
+        pytest.skip("crf_pydensecrf.npz not committed: run tests/golden/make_crf_golden.py where pydensecrf is installed")
+    g = np.load(path)
+    for i in range(int(g["n"])):
+        lab, q, _ = OP.densecrf(g[f"rgb_{i}"], g[f"maps_{i}"], want_q=True)
+        ref_q = g[f"Q_{i}"]
+        srt = np.sort(ref_q, axis=0)
+        tie = (srt[-1] - srt[-2]) < 1e-3                      # Eigen's exp vs include/pnp_math.h: near-tie tolerant
+        assert ((lab != g[f"labels_{i}"]) & ~tie).sum() == 0, i
+        assert np.abs(q - ref_q).max() < 5e-3, i
