@@ -39,7 +39,13 @@ typedef struct pnp_config {
     int32_t max_batch;      /* images per step (--batch_size, PnP.py:58) */
     int32_t max_text_len;   /* longest tokenised caption the engine must hold (<= 192) */
     int32_t stash_layer;    /* args.max_att_block_num - 1 (PnP.py:619): text layer whose P and dL/dP are kept */
-    int32_t compute_bf16;   /* 1: bf16 storage + fp32 accumulate MFMA; 0: exact fp32 MFMA (parity mode) */
+    int32_t compute_bf16;   /* arithmetic of the dense contractions:
+                             *   0  exact fp32 MFMA everywhere (the reference's arithmetic; parity mode)
+                             *   1  bf16 storage + bf16 MFMA with fp32 accumulation (throughput mode; ~1 % error on image_embeds)
+                             *   2  split-bf16 ("bf16x3"): ViT Linears and the cross K/V projections on (hi, lo) bf16 operand
+                             *      pairs, three bf16 MFMA passes per product with fp32 accumulation -- fp32-class results
+                             *      (maps within 1e-4 of mode 0, same patch picks) at ~5x the fp32 MFMA rate; attention,
+                             *      text stack, backward and post-processing as in mode 0 */
     int32_t device;         /* HIP device ordinal */
 } pnp_config;
 
@@ -74,6 +80,11 @@ int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const int64_t* d
 /* loss = logits[:,1].sum(); loss.backward() restricted to what reaches attention_probs of
  * stash_layer (B/blip_image_text_matching.py:399-404, hook B/med.py:164-168). */
 int pnp_xattn_grad(pnp_engine* e, int32_t B, int32_t L, void* stream);
+/* The same backward stopped at any kept layer (stash_layer <= layer < txt_layers): after it "P" / "dP" and
+ * pnp_gradcam_gather refer to that layer.  With stash_layer = 0 every [layer][head] entry of compute_gradcam_ensemble's
+ * return value (B/blip_image_text_matching.py:411-435; the drivers' --ensemble_blocks / layer-head sweep reads them) is
+ * available from one forward: one pnp_xattn_grad_layer + 12 gathers per layer. */
+int pnp_xattn_grad_layer(pnp_engine* e, int32_t B, int32_t L, int32_t layer, void* stream);
 /* cams * relu(grads) * mask for one head, [ENC] row and image-CLS column dropped
  * (B/blip_image_text_matching.py:427-433).  d_out: (B, L-1, P, P) fp32. */
 int pnp_gradcam_gather(pnp_engine* e, const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t head,
@@ -82,6 +93,11 @@ int pnp_gradcam_gather(pnp_engine* e, const int64_t* d_mask, int32_t ld, int32_t
 int pnp_compute_gradcam(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
                         const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t head, float* d_out,
                         float* d_logits, void* stream);
+
+/* ... for [layer][head], stash_layer <= layer (args.max_att_block_num - 1 chosen per call: layer / head sweeps). */
+int pnp_compute_gradcam_layer(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
+                              const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t layer, int32_t head,
+                              float* d_out, float* d_logits, void* stream);
 
 /* ---- salience-drop loop: replaces Inference_BLIP_filteredcaption (PnP.py:564-722) -------- */
 /* One bookkeeping step (PnP.py:619-647 + the running sum of :716-721) on a gathered map. */
@@ -93,6 +109,11 @@ int pnp_drop_step(pnp_engine* e, const float* d_gradcam, float* d_g0, float* d_a
 int pnp_drop_loop(pnp_engine* e, const float* d_images, const int64_t* d_ids, const int64_t* d_mask, int32_t ld,
                   int32_t B, int32_t L, int32_t head, int32_t drop_iter, int32_t npick, float* d_g0, float* d_agg,
                   int32_t* d_picks, float* d_logits, void* stream);
+
+/* The loop on the maps of another kept text layer (stash_layer <= layer). */
+int pnp_drop_loop_layer(pnp_engine* e, const float* d_images, const int64_t* d_ids, const int64_t* d_mask, int32_t ld,
+                        int32_t B, int32_t L, int32_t layer, int32_t head, int32_t drop_iter, int32_t npick, float* d_g0,
+                        float* d_agg, int32_t* d_picks, float* d_logits, void* stream);
 
 /* ---- post-process: replaces PnP.py:348-403 / 424-481 + postprocess/densecrf/scores ------ */
 typedef struct pnp_post_batch {
@@ -196,6 +217,16 @@ int pnp_op_gemm_ex(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, 
 int pnp_op_gemm_tokcols(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,
                         int32_t K, const float* d_bias_rows, void* d_out_t, int32_t ldo_t, int32_t col_div,
                         int32_t col_pad, void* stream);
+/* Split-bf16 ("bf16x3") form of the Linear (compute mode 2): operands are bf16 pairs x = hi + lo (pnp_op_split),
+ * out = A.B^T accumulated as A_hi.B_hi + A_hi.B_lo + A_lo.B_hi in fp32, then one of the fp32-facing epilogues:
+ *   d_out_f32, no col_div / bias_on_rows : + bias[n] (+ resid)            -> fp32 [M, ldo]
+ *   d_out_f32, bias_on_rows / col_div    : + bias[m], token-column remap  -> fp32 [M, ldo]   (as pnp_op_gemm_tokcols)
+ *   gelu, d_out_hi + d_out_lo            : + bias[n], erf GELU            -> split bf16 pair [M, ldo_t] */
+int pnp_op_split(const float* d_in, void* d_hi, void* d_lo, int64_t n, void* stream);
+int pnp_op_gemm_x3(const void* d_A_hi, const void* d_A_lo, int32_t lda, const void* d_B_hi, const void* d_B_lo, int32_t ldb,
+                   int32_t M, int32_t N, int32_t K, const float* d_bias, int32_t bias_on_rows, const float* d_resid, int32_t ldr,
+                   float* d_out_f32, int32_t ldo, void* d_out_hi, void* d_out_lo, int32_t ldo_t, int32_t gelu, int32_t col_div,
+                   int32_t col_pad, void* stream);
 /* ViT self-attention of one block (B/vit.py:93-117): ctx = softmax(q k^T * scale) v per (image, head), head_dim 64.
  * d_qk [B*N, ld_qk]: q of head h at column h*64, k at column D + h*64; d_ctx [B*N, D].
  * fp32 mode: d_vt [D, ld_vt] = V^T, row h*64+d, column b*n_pad + token (n_pad a multiple of 64, pad columns zero).

@@ -55,7 +55,8 @@ struct VitLayerW {
 
 struct pnp_engine {
     pnp_config c{};
-    int bf = 0;
+    int bf = 0;                // 1: bf16 storage / bf16 MFMA everywhere
+    int x3 = 0;                // 1: split-bf16 ("bf16x3") ViT Linears + cross K/V projections, everything else as fp32 mode
     size_t esz = 4;
     int P = 0, PP = 0, N = 0, Npad = 0, D = 0, H = 0, I = 0, TL = 0, nh = 0, Nst = 0, SL = 0;
     char err[512] = {0};
@@ -87,6 +88,7 @@ struct pnp_engine {
           *dctx_s = nullptr, *dS = nullptr, *dPc = nullptr;
     void *d_preT = nullptr, *dg = nullptr, *d_cpreT = nullptr, *dctxc = nullptr, *dqc = nullptr, *d_apreT = nullptr,
          *dqkv = nullptr;
+    int grad_layer = -1;       // text layer whose dL/dP the dPc buffer currently holds (-1: none)
     // drop loop
     float* G = nullptr;
     uint8_t* dropped = nullptr;
@@ -197,8 +199,9 @@ __global__ void transpose_cast_kernel_f32(const float* __restrict__ in, float* _
     }
 }
 
-// fp32 [rows, cols] staging -> compute-type device weight (optionally transposed)
-int make_weight(pnp_engine* e, const float* src32, int rows, int cols, bool transpose, void** out) {
+// fp32 [rows, cols] staging -> compute-type device weight (optionally transposed); split: a bf16 (hi | lo) pair in
+// the same bytes as the fp32 copy, hi first (split-bf16 mode, weights of the wide GEMMs)
+int make_weight(pnp_engine* e, const float* src32, int rows, int cols, bool transpose, void** out, bool split = false) {
     KCHK(e, dalloc_t(e, out, (size_t)rows * cols));
     const float* s = src32;
     float* tmp = nullptr;
@@ -208,7 +211,8 @@ int make_weight(pnp_engine* e, const float* src32, int rows, int cols, bool tran
                            rows, cols);
         s = tmp;
     }
-    int r = cast_f32(e->bf, s, *out, (size_t)rows * cols, 0);
+    int r = split ? split_f32(s, *out, (char*)*out + (size_t)rows * cols * 2, (size_t)rows * cols, 0)
+                  : cast_f32(e->bf, s, *out, (size_t)rows * cols, 0);
     hipError_t st = hipDeviceSynchronize();
     if (tmp) (void)hipFree(tmp);
     if (r != PNP_OK || st != hipSuccess) return fail(e, PNP_ERR_HIP, "weight conversion failed");
@@ -231,7 +235,7 @@ const char* kVitNames[] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "att
 
 extern "C" size_t pnp_workspace_bytes(const pnp_config* c) {
     if (!c) return 0;
-    const size_t es = c->compute_bf16 ? 2 : 4;
+    const size_t es = c->compute_bf16 == 1 ? 2 : 4;
     const size_t P = c->img_size / c->patch, N = P * P + 1, Npad = (N + 63) / 64 * 64, D = c->vit_dim, H = c->txt_hidden,
                  I = c->txt_inter, TL = c->txt_layers, B = c->max_batch, L = c->max_text_len;
     const size_t M = B * N, R = B * L;
@@ -263,7 +267,9 @@ extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
     *out = e;
     e->c = *cfg;
     const pnp_config& c = e->c;
-    e->bf = c.compute_bf16 ? 1 : 0;
+    if (c.compute_bf16 < 0 || c.compute_bf16 > 2) return fail(e, PNP_ERR_ARG, "compute_bf16 must be 0 (fp32), 1 (bf16) or 2 (split-bf16)");
+    e->bf = c.compute_bf16 == 1 ? 1 : 0;
+    e->x3 = c.compute_bf16 == 2 ? 1 : 0;
     e->esz = e->bf ? 2 : 4;
     if (c.patch != 16) return fail(e, PNP_ERR_ARG, "patch must be 16");
     if (c.img_size % 16 || c.img_size <= 0) return fail(e, PNP_ERR_ARG, "img_size must be a positive multiple of 16");
@@ -526,10 +532,10 @@ extern "C" int pnp_finalize_weights(pnp_engine* e) {
         NEED(w1, b + "attn.proj.weight");
         NEED(w2, b + "mlp.fc1.weight");
         NEED(w3, b + "mlp.fc2.weight");
-        KCHK(e, make_weight(e, w0, 3 * D, D, false, &e->vit[i].qkv_w));
-        KCHK(e, make_weight(e, w1, D, D, false, &e->vit[i].proj_w));
-        KCHK(e, make_weight(e, w2, F, D, false, &e->vit[i].fc1_w));
-        KCHK(e, make_weight(e, w3, D, F, false, &e->vit[i].fc2_w));
+        KCHK(e, make_weight(e, w0, 3 * D, D, false, &e->vit[i].qkv_w, e->x3));
+        KCHK(e, make_weight(e, w1, D, D, false, &e->vit[i].proj_w, e->x3));
+        KCHK(e, make_weight(e, w2, F, D, false, &e->vit[i].fc1_w, e->x3));
+        KCHK(e, make_weight(e, w3, D, F, false, &e->vit[i].fc2_w, e->x3));
     }
     // cross-attention K / V weights of all layers, layer-major, so one GEMM projects every layer
     KCHK(e, dalloc_t(e, &e->ck_w, (size_t)TL * H * D));
@@ -570,8 +576,14 @@ extern "C" int pnp_finalize_weights(pnp_engine* e) {
         KCHK(e, make_weight(e, wco, H, H, false, &t.co_w));
         KCHK(e, make_weight(e, wi, I, H, false, &t.i_w));
         KCHK(e, make_weight(e, wo, H, I, false, &t.o_w));
-        KCHK(e, cast_f32(e->bf, wck, (char*)e->ck_w + (size_t)i * H * D * e->esz, (size_t)H * D, 0));
-        KCHK(e, cast_f32(e->bf, wcv, (char*)e->cv_w + (size_t)i * H * D * e->esz, (size_t)H * D, 0));
+        if (e->x3) {               // (hi | lo) halves over all layers: hi[TL*H*D] then lo[TL*H*D]
+            const size_t half = (size_t)TL * H * D * 2, off = (size_t)i * H * D * 2;
+            KCHK(e, split_f32(wck, (char*)e->ck_w + off, (char*)e->ck_w + half + off, (size_t)H * D, 0));
+            KCHK(e, split_f32(wcv, (char*)e->cv_w + off, (char*)e->cv_w + half + off, (size_t)H * D, 0));
+        } else {
+            KCHK(e, cast_f32(e->bf, wck, (char*)e->ck_w + (size_t)i * H * D * e->esz, (size_t)H * D, 0));
+            KCHK(e, cast_f32(e->bf, wcv, (char*)e->cv_w + (size_t)i * H * D * e->esz, (size_t)H * D, 0));
+        }
         if (i >= e->SL) {
             KCHK(e, make_weight(e, wo, H, I, true, &t.o_wT));      // [I][H]
             KCHK(e, make_weight(e, wi, I, H, true, &t.i_wT));      // [H][I]
@@ -611,6 +623,55 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
         KCHK(e, gemm_nt(bf, g, s));
     }
     const float scale = 1.0f / sqrtf(64.f);
+    if (e->x3) {
+        // split-bf16 ("bf16x3"): every Linear of the block is a wide-kernel launch on (hi, lo) bf16 operand pairs -- three
+        // bf16 MFMA passes per product, fp32-class result; LayerNorm, the attention kernel and the GELU epilogue hand the
+        // next GEMM its operand already split.  Attention itself runs in the exact-fp32 kernel.
+        const size_t cap = (size_t)e->c.max_batch * N;                    // row capacity of the activation buffers
+        void* const xn_lo = (char*)e->xn + cap * D * 2;
+        void* const ctx_lo = (char*)e->ctx + cap * D * 2;
+        void* const h1_lo = (char*)e->h1 + cap * F * 2;
+        for (int l = 0; l < e->c.vit_depth; l++) {
+            const VitLayerW& w = e->vit[l];
+            const char* const qkv_lo = (const char*)w.qkv_w + (size_t)3 * D * D * 2;
+            KCHK(e, layernorm(1, e->x, w.n1w, w.n1b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s, xn_lo));
+            {   // q | k natural, fp32: [M, 2D]
+                GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 2 * D, D);
+                g.A_lo = xn_lo; g.B_lo = qkv_lo;
+                g.bias = w.qkv_b; g.out_f32 = (float*)e->qk; g.ldo = 2 * D;
+                KCHK(e, gemm_nt(1, g, s));
+            }
+            {   // V^T fp32: [D, B*Npad] = Wv . xn^T, token columns padded per image
+                GemmArgs g = G_((const char*)w.qkv_w + (size_t)2 * D * D * 2, D, e->xn, D, D, M, D);
+                g.A_lo = qkv_lo + (size_t)2 * D * D * 2; g.B_lo = xn_lo;
+                g.bias = w.qkv_b + 2 * D; g.bias_on_rows = 1; g.out_f32 = (float*)e->vt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
+                KCHK(e, gemm_nt(1, g, s));
+            }
+            KCHK(e, vit_attention(0, e->qk, 2 * D, D, e->vt, ldv, e->Npad, e->ctx, B, e->c.vit_heads, N, scale, s, ctx_lo));
+            {
+                GemmArgs g = G_(e->ctx, D, w.proj_w, D, M, D, D);
+                g.A_lo = ctx_lo; g.B_lo = (const char*)w.proj_w + (size_t)D * D * 2;
+                g.bias = w.proj_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
+                KCHK(e, gemm_nt(1, g, s));
+            }
+            KCHK(e, layernorm(1, e->x, w.n2w, w.n2b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s, xn_lo));
+            {
+                GemmArgs g = G_(e->xn, D, w.fc1_w, D, M, F, D);
+                g.A_lo = xn_lo; g.B_lo = (const char*)w.fc1_w + (size_t)F * D * 2;
+                g.bias = w.fc1_b; g.mode = GEMM_EPI_GELU; g.out_t = e->h1; g.out_lo = h1_lo; g.ldo_t = F;
+                KCHK(e, gemm_nt(1, g, s));
+            }
+            {
+                GemmArgs g = G_(e->h1, F, w.fc2_w, F, M, D, F);
+                g.A_lo = h1_lo; g.B_lo = (const char*)w.fc2_w + (size_t)D * F * 2;
+                g.bias = w.fc2_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
+                KCHK(e, gemm_nt(1, g, s));
+            }
+        }
+        KCHK(e, layernorm(1, e->x, e->vnorm_w, e->vnorm_b, e->c.vit_ln_eps, M, D, e->emb32, e->embT, nullptr, nullptr, s,
+                          (char*)e->embT + cap * D * 2));
+        return pnp_cross_kv(e, B, stream);
+    }
     for (int l = 0; l < e->c.vit_depth; l++) {
         const VitLayerW& w = e->vit[l];
         KCHK(e, layernorm(bf, e->x, w.n1w, w.n1b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s));
@@ -665,6 +726,40 @@ extern "C" int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream) {
     const int D = e->D, N = e->N, M = B * N, bf = e->bf;
     const int ldv = e->c.max_batch * e->Npad;
     const int H = e->H, TL = e->TL, SL = e->SL;
+    if (e->x3) {
+        const size_t cap = (size_t)e->c.max_batch * N, whalf = (size_t)TL * H * D * 2;
+        const void* const emb_lo = (const char*)e->embT + cap * D * 2;
+        const char *ck = (const char*)e->ck_w, *cv = (const char*)e->cv_w;
+        {
+            GemmArgs g = G_(e->embT, D, ck, D, M, TL * H, D);
+            g.A_lo = emb_lo; g.B_lo = ck + whalf;
+            g.bias = e->ck_b; g.out_f32 = (float*)e->Knat; g.ldo = TL * H;
+            KCHK(e, gemm_nt(1, g, s));
+        }
+        {
+            GemmArgs g = G_(cv, D, e->embT, D, TL * H, M, D);
+            g.A_lo = cv + whalf; g.B_lo = emb_lo;
+            g.bias = e->cv_b; g.bias_on_rows = 1; g.out_f32 = (float*)e->Vt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
+            KCHK(e, gemm_nt(1, g, s));
+        }
+        {
+            const int nVn = TL - SL;
+            const size_t off = (size_t)SL * H * D * 2;
+            GemmArgs g = G_(e->embT, D, cv + off, D, M, nVn * H, D);
+            g.A_lo = emb_lo; g.B_lo = cv + whalf + off;
+            g.bias = e->cv_b + (size_t)SL * H; g.out_f32 = (float*)e->Vnat; g.ldo = nVn * H;
+            KCHK(e, gemm_nt(1, g, s));
+        }
+        if (TL - SL - 1 > 0) {
+            const int nKt = TL - SL - 1;
+            const size_t off = (size_t)(SL + 1) * H * D * 2;
+            GemmArgs g = G_(ck + off, D, e->embT, D, nKt * H, M, D);
+            g.A_lo = ck + whalf + off; g.B_lo = emb_lo;
+            g.bias = e->ck_b + (size_t)(SL + 1) * H; g.bias_on_rows = 1; g.out_f32 = (float*)e->Kt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
+            KCHK(e, gemm_nt(1, g, s));
+        }
+        return PNP_OK;
+    }
     {
         GemmArgs g = G_(e->embT, D, e->ck_w, D, M, TL * H, D);
         g.bias = e->ck_b; g.out_t = e->Knat; g.ldo_t = TL * H;
@@ -753,14 +848,21 @@ extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const
 }
 
 extern "C" int pnp_xattn_grad(pnp_engine* e, int32_t B, int32_t L, void* stream) {
+    return pnp_xattn_grad_layer(e, B, L, e ? e->SL : 0, stream);
+}
+
+extern "C" int pnp_xattn_grad_layer(pnp_engine* e, int32_t B, int32_t L, int32_t layer, void* stream) {
     if (!e) return PNP_ERR_ARG;
     if (!e->finalized) return fail(e, PNP_ERR_STATE, "weights not finalized");
     if (B <= 0 || B > e->c.max_batch || L < 5 || L > e->c.max_text_len) return fail(e, PNP_ERR_ARG, "bad B/L");
+    if (layer < e->SL || layer >= e->TL)
+        return fail(e, PNP_ERR_ARG, "layer %d: cross-attention maps are kept for text layers %d..%d (stash_layer)", layer, e->SL, e->TL - 1);
     hipStream_t s = (hipStream_t)stream;
     const int H = e->H, I = e->I, TL = e->TL, R = B * L, bf = e->bf, N = e->N, SL = e->SL;
     const int ldv = e->c.max_batch * e->Npad, nVn = TL - SL;
+    e->grad_layer = layer;
     KCHK(e, itm_grad_seed(e->itm_w, e->dh, B, L, H, s));
-    for (int i = TL - 1; i >= SL; i--) {
+    for (int i = TL - 1; i >= layer; i--) {
         const TextLayerW& w = e->txt[i];
         TextLayerA& a = e->ta[i];
         KCHK(e, layernorm_bwd(bf, e->dh, w.oln_w, a.o_hat, a.o_rstd, R, H, e->d_pre, e->d_preT, s));
@@ -781,7 +883,7 @@ extern "C" int pnp_xattn_grad(pnp_engine* e, int32_t B, int32_t L, void* stream)
             KCHK(e, gemm_nt(bf, g, s));
         }
         const char* vnat = (const char*)e->Vnat + (size_t)(i - SL) * H * e->esz;
-        if (i == SL) {
+        if (i == layer) {
             KCHK(e, xattn(bf, 2, vnat, nVn * H, nullptr, 0, e->Npad, e->dctxc, H, nullptr, 0, e->dPc, e->Nst, B, L, N, e->nh, s));
             break;
         }
@@ -813,20 +915,28 @@ extern "C" int pnp_gradcam_gather(pnp_engine* e, const int64_t* d_mask, int32_t 
     if (!e || !d_mask || !d_out) return PNP_ERR_ARG;
     if (head < 0 || head >= e->nh) return fail(e, PNP_ERR_ARG, "head %d out of range", head);
     if (B <= 0 || B > e->c.max_batch || L < 5 || L > e->c.max_text_len || ld < L) return fail(e, PNP_ERR_ARG, "bad B/L/ld");
-    KCHK(e, gradcam_gather(e->ta[e->SL].Pc, e->dPc, d_mask, ld, d_out, B, e->nh, head, L, e->Nst, e->PP, (hipStream_t)stream));
+    if (e->grad_layer < 0) return fail(e, PNP_ERR_STATE, "call pnp_xattn_grad first");
+    // P of the layer the last backward stopped at, and its dL/dP
+    KCHK(e, gradcam_gather(e->ta[e->grad_layer].Pc, e->dPc, d_mask, ld, d_out, B, e->nh, head, L, e->Nst, e->PP, (hipStream_t)stream));
     return PNP_OK;
+}
+
+extern "C" int pnp_compute_gradcam_layer(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
+                                         const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t layer, int32_t head,
+                                         float* d_out, float* d_logits, void* stream) {
+    int r = pnp_vit_forward(e, d_images, d_dropped, B, stream);
+    if (r) return r;
+    r = pnp_text_forward_xattn(e, d_ids, d_mask, ld, B, L, d_logits, stream);
+    if (r) return r;
+    r = pnp_xattn_grad_layer(e, B, L, layer, stream);
+    if (r) return r;
+    return pnp_gradcam_gather(e, d_mask, ld, B, L, head, d_out, stream);
 }
 
 extern "C" int pnp_compute_gradcam(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
                                    const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t head, float* d_out,
                                    float* d_logits, void* stream) {
-    int r = pnp_vit_forward(e, d_images, d_dropped, B, stream);
-    if (r) return r;
-    r = pnp_text_forward_xattn(e, d_ids, d_mask, ld, B, L, d_logits, stream);
-    if (r) return r;
-    r = pnp_xattn_grad(e, B, L, stream);
-    if (r) return r;
-    return pnp_gradcam_gather(e, d_mask, ld, B, L, head, d_out, stream);
+    return pnp_compute_gradcam_layer(e, d_images, d_dropped, d_ids, d_mask, ld, B, L, e ? e->SL : 0, head, d_out, d_logits, stream);
 }
 
 extern "C" int pnp_drop_step(pnp_engine* e, const float* d_gradcam, float* d_g0, float* d_agg, uint8_t* d_dropped,
@@ -841,15 +951,22 @@ extern "C" int pnp_drop_step(pnp_engine* e, const float* d_gradcam, float* d_g0,
 extern "C" int pnp_drop_loop(pnp_engine* e, const float* d_images, const int64_t* d_ids, const int64_t* d_mask, int32_t ld,
                              int32_t B, int32_t L, int32_t head, int32_t drop_iter, int32_t npick, float* d_g0,
                              float* d_agg, int32_t* d_picks, float* d_logits, void* stream) {
+    return pnp_drop_loop_layer(e, d_images, d_ids, d_mask, ld, B, L, e ? e->SL : 0, head, drop_iter, npick, d_g0, d_agg, d_picks,
+                               d_logits, stream);
+}
+
+extern "C" int pnp_drop_loop_layer(pnp_engine* e, const float* d_images, const int64_t* d_ids, const int64_t* d_mask, int32_t ld,
+                                   int32_t B, int32_t L, int32_t layer, int32_t head, int32_t drop_iter, int32_t npick, float* d_g0,
+                                   float* d_agg, int32_t* d_picks, float* d_logits, void* stream) {
     if (!e || !d_images || !d_ids || !d_mask || !d_g0) return PNP_ERR_ARG;
     if (drop_iter < 1) return fail(e, PNP_ERR_ARG, "drop_iter must be >= 1");
     if (drop_iter == 1)   // PnP.py:565-575: single call, no aggregate
-        return pnp_compute_gradcam(e, d_images, nullptr, d_ids, d_mask, ld, B, L, head, d_g0, d_logits, stream);
+        return pnp_compute_gradcam_layer(e, d_images, nullptr, d_ids, d_mask, ld, B, L, layer, head, d_g0, d_logits, stream);
     if (!d_agg || !d_picks) return PNP_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(e, hipMemsetAsync(e->dropped, 0, (size_t)B * e->PP, s));
     for (int it = 0; it < drop_iter; it++) {
-        int r = pnp_compute_gradcam(e, d_images, e->dropped, d_ids, d_mask, ld, B, L, head, e->G, d_logits, stream);
+        int r = pnp_compute_gradcam_layer(e, d_images, e->dropped, d_ids, d_mask, ld, B, L, layer, head, e->G, d_logits, stream);
         if (r) return r;
         r = pnp_drop_step(e, e->G, d_g0, d_agg, e->dropped, d_picks, it, B, L - 1, npick, drop_iter * npick, stream);
         if (r) return r;
@@ -1260,7 +1377,7 @@ extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, siz
     if (n == "image_embeds") return set(e->emb32, B * e->N * (size_t)e->D * 4);
     if (n == "image_embeds_t") return set(e->embT, B * e->N * (size_t)e->D * e->esz);
     if (n == "x") return set(e->x, B * e->N * (size_t)e->D * 4);
-    if (n == "P") return set(e->ta[e->SL].Pc, B * e->nh * L * (size_t)e->Nst * 4);
+    if (n == "P") return set(e->ta[e->grad_layer >= 0 ? e->grad_layer : e->SL].Pc, B * e->nh * L * (size_t)e->Nst * 4);
     if (n == "dP") return set(e->dPc, B * e->nh * L * (size_t)e->Nst * 4);
     if (n == "h_last") return set(e->ta[e->TL - 1].h_out, B * L * (size_t)e->H * 4);
     if (n == "dropped") return set(e->dropped, B * (size_t)e->PP);
@@ -1349,6 +1466,24 @@ extern "C" int pnp_op_gemm_ex(int32_t bf, const void* d_A, int32_t lda, const vo
     g.bias = d_bias; g.resid = d_resid; g.ldr = ldr; g.out_f32 = d_out_f32; g.ldo = ldo; g.out_t = d_out_t; g.ldo_t = ldo_t;
     g.mode = mode ? GEMM_EPI_GELU : GEMM_EPI_LINEAR;
     return gemm_nt(bf, g, (hipStream_t)stream);
+}
+
+extern "C" int pnp_op_split(const float* d_in, void* d_hi, void* d_lo, int64_t n, void* stream) {
+    if (!d_in || !d_hi || !d_lo || n <= 0) return PNP_ERR_ARG;
+    return split_f32(d_in, d_hi, d_lo, (size_t)n, (hipStream_t)stream);
+}
+
+extern "C" int pnp_op_gemm_x3(const void* d_A_hi, const void* d_A_lo, int32_t lda, const void* d_B_hi, const void* d_B_lo,
+                              int32_t ldb, int32_t M, int32_t N, int32_t K, const float* d_bias, int32_t bias_on_rows,
+                              const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, void* d_out_hi, void* d_out_lo,
+                              int32_t ldo_t, int32_t gelu, int32_t col_div, int32_t col_pad, void* stream) {
+    if (!d_A_hi || !d_A_lo || !d_B_hi || !d_B_lo) return PNP_ERR_ARG;
+    GemmArgs g = G_(d_A_hi, lda, d_B_hi, ldb, M, N, K);
+    g.A_lo = d_A_lo; g.B_lo = d_B_lo;
+    g.bias = d_bias; g.bias_on_rows = bias_on_rows; g.resid = d_resid; g.ldr = ldr; g.out_f32 = d_out_f32; g.ldo = ldo;
+    g.out_t = d_out_hi; g.out_lo = d_out_lo; g.ldo_t = ldo_t; g.col_div = col_div; g.col_pad = col_pad;
+    g.mode = gelu ? GEMM_EPI_GELU : GEMM_EPI_LINEAR;
+    return gemm_nt(1, g, (hipStream_t)stream);
 }
 
 extern "C" int pnp_op_gemm_tokcols(int32_t bf, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,

@@ -22,10 +22,15 @@ struct GemmArgs {
     int ldo_t = 0;
     float* aux = nullptr;          // GELU: pre-activation stash (f32) ; GELU_GRAD: pre-activation input
     int ld_aux = 0;
+    // split-bf16 ("bf16x3") form of the wide kernel: A = A (hi) + A_lo, B = B (hi) + B_lo, all bf16, and the product is
+    // accumulated as A.B + A.B_lo + A_lo.B on the bf16 MFMA in fp32 (the dropped A_lo.B_lo term is 2^-18 relative)
+    const void* A_lo = nullptr;    // [M, lda] bf16
+    const void* B_lo = nullptr;    // [N, ldb] bf16
+    void* out_lo = nullptr;        // optional bf16 low part of a split output [*, ldo_t] (out_t holds the high part)
     int row_div = 0;               // >0: patch rows -> token rows b*(row_div+1)+1+p, resid = pos_embed
     int col_div = 0, col_pad = 0;  // >0: output column n -> (n / col_div) * col_pad + n % col_div
-    unsigned long long* stamps = nullptr;   // diagnostics (PNP_GEMM_STAMPS): per-workgroup clock stamps, 8 per block
-    int ablate = 0;                // timing experiments only (PNP_GEMM_ABLATE): 1 = no steady-state DMA, 2 = no MFMA
+    unsigned long long* stamps = nullptr;   // diagnostics (DEV builds, PNP_GEMM_STAMPS): per-workgroup clock stamps, 8 per block
+    int ablate = 0;                // DEV builds only (PNP_GEMM_ABLATE): 1 = no steady-state DMA, 2 = no MFMA
 };
 
 int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s);

@@ -175,7 +175,9 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
         }
     }
     auto issue = [&](int kt) {
+#ifdef PNP_DEV
         if (g.ablate == 1 && kt >= NS) return;           // timing ablation: no steady-state DMA
+#endif
         char* stage = smem + (kt % NS) * STAGE;
         const uint32_t koff = (uint32_t)kt * ROWB;
 #pragma unroll
@@ -246,12 +248,15 @@ __global__ __launch_bounds__((BM / WTM) * (BN / WTN) * 64) void gemm_nt_big_kern
             const char* cB = cA + BM * ROWB;
 #pragma unroll
             for (int j = 0; j < TM; j++) {
-                if (g.ablate != 2) {
-#pragma unroll
-                    for (int i = 0; i < TN; i++) mma16(acc[i][j], fb_cur[i], fa_cur[j]);
-                } else {                                     // timing ablation: no MFMA, operands kept alive
+#ifdef PNP_DEV
+                if (g.ablate == 2) {                         // timing ablation: no MFMA, operands kept alive
 #pragma unroll
                     for (int i = 0; i < TN; i++) asm volatile("" ::"v"(fb_cur[i].v), "v"(fa_cur[j].v));
+                } else
+#endif
+                {
+#pragma unroll
+                    for (int i = 0; i < TN; i++) mma16(acc[i][j], fb_cur[i], fa_cur[j]);
                 }
                 if (have_next) {
                     lds_frag<ROWB>(fa_cur[j], cA, wm * WTM + j * 16 + r, ks_n, q);
@@ -379,12 +384,19 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 
 // EPI: 0 = +bias -> bf16 | 1 = +bias, GELU -> bf16 | 2 = +bias +residual -> fp32 |
 //      3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (transposed cross-attention K / V)
-enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3 };
+//      4 = +bias -> fp32 | 5 = as 3 with fp32 output | 6 = +bias, GELU (erf form) -> split bf16 pair (hi, lo)
+// X3 (split-bf16, "bf16x3"): the operands are bf16 pairs a = a_hi + a_lo, b = b_hi + b_lo and the k loop runs three
+// times over K -- (a_hi, b_hi), (a_hi, b_lo), (a_lo, b_hi) -- into the same fp32 accumulators: an fp32-class product
+// (terms dropped: a_lo.b_lo, 2^-18 relative, and what two bf16 cannot hold of an fp32 operand, 2^-17) at a third of
+// the bf16 MFMA rate, i.e. ~5x the fp32 MFMA rate (v_mfma_f32_16x16x4_f32 runs at 1/16 of bf16).  Only the slab ->
+// source-array map of the DMA changes; the MFMA stream is the bf16 kernel's.
+enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3, WIDE_BIAS_F32 = 4, WIDE_TOKCOLS_F32 = 5,
+       WIDE_GELU_SPLIT = 6 };
 constexpr int kWideStageRow = 68;                                  // floats per staged row (64 + 4 pad)
 constexpr int kWideStageBytes = 8 * 32 * kWideStageRow * 4;        // 8 waves x 32 rows
 constexpr int kWideSmem = 65536 + kWideStageBytes;                 // slot 0 | slot 1 overlaid by the staging area
 
-template <int EPI>
+template <int EPI, bool X3>
 __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, ROWB = 128, BK = 64, STAGE = (BM + BN) * ROWB;
     constexpr int TM = 4, TN = 2;                   // 32 x 32 tiles per wave: 128 (m) x 64 (n)
@@ -398,9 +410,12 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     const int wm = wave >> 2, wn = wave & 3;
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const int ntiles = nbm * nbn;
-    const int nk = g.K / BK;
+    const int nk0 = g.K / BK;
+    const int nk = X3 ? 3 * nk0 : nk0;
     const char* Ab = reinterpret_cast<const char*>(g.A);
     const char* Bb = reinterpret_cast<const char*>(g.B);
+    const char* Alo = reinterpret_cast<const char*>(g.A_lo);
+    const char* Blo = reinterpret_cast<const char*>(g.B_lo);
 
     uint32_t soff[NDMA];
     auto set_tile = [&](int tile, int& m0, int& n0) {
@@ -427,8 +442,16 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     };
     auto issue_one = [&](int kt, int i) {
         char* stage = smem + (kt & 1) * STAGE;
-        const uint32_t koff = (uint32_t)kt * ROWB;
-        const char* base = i < A_DMA ? Ab : Bb;
+        int kk = kt;
+        const char *abase = Ab, *bbase = Bb;
+        if constexpr (X3) {                         // slab kt of 3 nk0: (hi, hi) | (hi, lo) | (lo, hi) over the same K
+            const int seg = kt >= 2 * nk0 ? 2 : (kt >= nk0 ? 1 : 0);
+            kk = kt - seg * nk0;
+            abase = seg == 2 ? Alo : Ab;
+            bbase = seg == 1 ? Blo : Bb;
+        }
+        const uint32_t koff = (uint32_t)kk * ROWB;
+        const char* base = i < A_DMA ? abase : bbase;
         const int d = i < A_DMA ? (wave * A_DMA + i) * 8 * ROWB : BM * ROWB + (wave * B_DMA + (i - A_DMA)) * 8 * ROWB;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[i] + koff)),
                                          (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
@@ -558,7 +581,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         f32x4 rv[8];
         f32x4 bacc[TN][4];                          // bf16 epilogues: bias in the accumulator layout
-        if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16) {
+        if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16 || EPI == WIDE_GELU_SPLIT) {
 #pragma unroll
             for (int i = 0; i < TN; i++)
 #pragma unroll
@@ -566,6 +589,9 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                     const int nn = en0 + wn * 64 + i * 32 + gq * 8 + hi * 4;
                     bacc[i][gq] = (g.bias && nn < g.Nvalid) ? *reinterpret_cast<const f32x4*>(g.bias + nn) : bv;
                 }
+        }
+        if constexpr (EPI == WIDE_BIAS_F32) {
+            if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
         }
         if constexpr (EPI == WIDE_RESID_F32) {
             if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
@@ -579,7 +605,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
             }
         }
         float brow[TM] = {0.f, 0.f, 0.f, 0.f};        // TOKCOLS: bias of this lane's row in each 32-row tile
-        if constexpr (EPI == WIDE_TOKCOLS_BF16) {
+        if constexpr (EPI == WIDE_TOKCOLS_BF16 || EPI == WIDE_TOKCOLS_F32) {
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const int m = em0 + wm * 128 + j * 32 + l32;
@@ -642,6 +668,97 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                     }
                 }
             }
+        } else if constexpr (EPI == WIDE_TOKCOLS_F32) {
+            // as above with an fp32 output (the split-bf16 mode feeds fp32 attention kernels): 32-row quarters staged as
+            // fp32 with the row bias added in the accumulator layout; a lane owns a pair of token columns (8-byte stores,
+            // 256 contiguous bytes per row) when col_div is even, else single tokens
+            const bool pairs = (g.col_div & 1) == 0;
+            const int tl0 = pairs ? 2 * l32 : lane;
+            const int tok = en0 + wn * 64 + tl0;
+            size_t ocol = tok;
+            if (g.col_div > 0) {
+                const int b = tok / g.col_div;
+                const int tl = tok - b * g.col_div;
+                ocol = (size_t)b * g.col_pad + tl;
+            }
+            float* const ocolp = g.out_f32 + ocol;
+            const bool tv = tok < g.Nvalid;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const int mbase = em0 + wm * 128 + qd * 32;
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++) {
+                        const f32x16& a = acc[i][qd];
+                        const float br = brow[qd];
+                        const f32x4 v = {a[gq * 4] + br, a[gq * 4 + 1] + br, a[gq * 4 + 2] + br, a[gq * 4 + 3] + br};
+                        *reinterpret_cast<f32x4*>(stg + l32 * SROW + i * 32 + gq * 8 + hi * 4) = v;
+                    }
+                if (pairs) {
+                    f32x2 sv[16];
+#pragma unroll
+                    for (int it = 0; it < 16; it++) sv[it] = *reinterpret_cast<const f32x2*>(stg + (it * 2 + hi) * SROW + tl0);
+#pragma unroll
+                    for (int it = 0; it < 16; it++) {
+                        const int m = mbase + it * 2 + hi;
+                        if (tv && m < g.M) *reinterpret_cast<f32x2*>(ocolp + (size_t)m * g.ldo) = sv[it];
+                    }
+                } else {
+#pragma unroll 8
+                    for (int row = 0; row < 32; row++) {
+                        const float v = stg[row * SROW + lane];
+                        if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo] = v;
+                    }
+                }
+            }
+        } else if constexpr (EPI == WIDE_GELU_SPLIT) {
+            // bias + erf-form GELU (|erf error| <= 1.5e-7) in the accumulator layout, written back into the accumulators;
+            // then two passes over the bf16 staging of the plain bf16 epilogue: hi = bf16(v) -> out_t, lo = bf16(v - hi)
+            // -> out_lo (the pair carries 16 significant bits of v)
+            constexpr int HROW = 68;
+            bf16* const stgh = reinterpret_cast<bf16*>(smem + 65536) + wave * (64 * HROW);
+            const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+#pragma unroll
+            for (int j = 0; j < TM; j++)
+#pragma unroll
+                for (int i = 0; i < TN; i++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[i][j][gq * 4 + e] = gelu_erf_fast(acc[i][j][gq * 4 + e] + bacc[i][gq][e]);
+#pragma unroll
+            for (int part = 0; part < 2; part++) {
+                bf16* const obase = reinterpret_cast<bf16*>(part ? g.out_lo : g.out_t) + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo_t + n;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+                        for (int i = 0; i < TN; i++)
+#pragma unroll
+                            for (int gq = 0; gq < 4; gq++) {
+                                const f32x16& a = acc[i][half * 2 + jj];
+                                bf16x4 pk;
+#pragma unroll
+                                for (int e = 0; e < 4; e++) {
+                                    const float v = a[gq * 4 + e];
+                                    const bf16 h = (bf16)v;
+                                    pk[e] = part ? (bf16)(v - (float)h) : h;
+                                }
+                                *reinterpret_cast<bf16x4*>(stgh + (jj * 32 + l32) * HROW + i * 32 + gq * 8 + hi * 4) = pk;
+                            }
+                    bf16x4 sv[16];
+#pragma unroll
+                    for (int it = 0; it < 16; it++)
+                        sv[it] = *reinterpret_cast<const bf16x4*>(stgh + (it * 4 + (lane >> 4)) * HROW + (lane & 15) * 4);
+#pragma unroll
+                    for (int it = 0; it < 16; it++) {
+                        const int m = em0 + wm * 128 + half * 64 + it * 4 + (lane >> 4);
+                        if (full || (m < g.M && nv)) *reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t) = sv[it];
+                    }
+                }
+            }
         } else if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16) {
             // bias (+GELU) and the bf16 rounding happen in the accumulator layout; the tile is staged as bf16
             // (half the LDS bytes: LDS stores run at ~80 B/clk/CU) in two 64-row halves, 136-byte rows so the
@@ -688,8 +805,9 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
             // fp32 residual epilogue, 32-row quarters staged as fp32.  The residual rows of quarter q+1 are
             // requested before the stores of quarter q (two register sets), so each wait has a whole quarter
             // of work in front of it and never sits behind a store.
+            constexpr bool kResid = EPI == WIDE_RESID_F32;      // WIDE_BIAS_F32: same path without the residual rows
             const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
-            const float* const rbase = g.resid + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldr + n;
+            const float* const rbase = kResid ? g.resid + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldr + n : nullptr;
             float* const obase = g.out_f32 + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo + n;
             f32x4 rw[8];
 #pragma unroll
@@ -704,7 +822,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                         const f32x4 v = {a[gq * 4], a[gq * 4 + 1], a[gq * 4 + 2], a[gq * 4 + 3]};
                         *reinterpret_cast<f32x4*>(stg + l32 * SROW + i * 32 + gq * 8 + hi * 4) = v;
                     }
-                if (qd < 3) {
+                if (kResid && qd < 3) {
 #pragma unroll
                     for (int it = 0; it < 8; it++) {
                         const int m = em0 + wm * 128 + (qd + 1) * 32 + it * 4 + (lane >> 4);
@@ -717,7 +835,8 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                     sv[it] = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 4);
 #pragma unroll
                 for (int it = 0; it < 8; it++) {
-                    const f32x4 v = sv[it] + bv + rcur[it];
+                    f32x4 v = sv[it] + bv;
+                    if constexpr (kResid) v += rcur[it];
                     const int m = em0 + wm * 128 + qd * 32 + it * 4 + (lane >> 4);
                     if (full || (m < g.M && nv)) *reinterpret_cast<f32x4*>(obase + (size_t)(qd * 32 + it * 4) * g.ldo) = v;
                 }
@@ -737,6 +856,16 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 // remaps, per-row bias, stashes, dual outputs) stays on the generic kernels
 static int wide_epilogue_kind(const GemmArgs& g) {
     if (g.aux || g.row_div) return -1;
+    if (g.A_lo || g.B_lo) {                         // split-bf16 operands: the fp32-facing epilogues
+        if (!g.A_lo || !g.B_lo) return -1;
+        if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_f32 && !g.out_t && (g.bias_on_rows || !g.bias) && (g.col_div > 0 || g.bias_on_rows))
+            return WIDE_TOKCOLS_F32;
+        if (g.col_div || g.bias_on_rows || (g.Nvalid & 3)) return -1;
+        if (g.mode == GEMM_EPI_LINEAR && g.resid && g.out_f32 && !g.out_t) return WIDE_RESID_F32;
+        if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_f32 && !g.out_t) return WIDE_BIAS_F32;
+        if (g.mode == GEMM_EPI_GELU && !g.resid && g.out_t && g.out_lo && !g.out_f32) return WIDE_GELU_SPLIT;
+        return -1;
+    }
     if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_t && !g.out_f32 && (g.bias_on_rows || !g.bias) && (g.col_div > 0 || g.bias_on_rows))
         return WIDE_TOKCOLS_BF16;
     if (g.col_div || g.bias_on_rows || (g.Nvalid & 3)) return -1;
@@ -746,7 +875,7 @@ static int wide_epilogue_kind(const GemmArgs& g) {
     return -1;
 }
 
-template <int EPI>
+template <int EPI, bool X3>
 static int launch_wide(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
     static int n_cu = 0;
@@ -756,17 +885,16 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return PNP_ERR_HIP;
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    static const int persist = getenv("PNP_GEMM_PERSIST") ? atoi(getenv("PNP_GEMM_PERSIST")) : 1;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 kWideSmem) != hipSuccess)
             return PNP_ERR_HIP;
         attr_set = true;
     }
     const int ntiles = nbm * nbn;
-    const int grid = (persist && ntiles > n_cu) ? n_cu : ntiles;      // one workgroup per CU (LDS-limited) walks the tiles
-    hipLaunchKernelGGL(gemm_nt_wide_kernel<EPI>, dim3(grid), dim3(512), kWideSmem, s, g);
+    const int grid = ntiles > n_cu ? n_cu : ntiles;      // one workgroup per CU (LDS-limited) walks the tiles
+    hipLaunchKernelGGL((gemm_nt_wide_kernel<EPI, X3>), dim3(grid), dim3(512), kWideSmem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
@@ -906,31 +1034,52 @@ static unsigned long long*& stamp_buf() {
     return p;
 }
 int gemm_read_stamps(unsigned long long* host_out, int max_blocks) {
-    if (!stamp_buf()) return PNP_ERR_STATE;
+    if (!stamp_buf()) return PNP_ERR_STATE;              // product builds never allocate it (see PNP_DEV above)
     const int n = max_blocks < kStampBlocks ? max_blocks : kStampBlocks;
     if (hipDeviceSynchronize() != hipSuccess) return PNP_ERR_HIP;
     return hipMemcpy(host_out, stamp_buf(), (size_t)n * 64, hipMemcpyDeviceToHost) == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
+// Development knobs (timing ablations, forced tile variants, in-kernel clock stamps) exist only in builds made with
+// `make DEV=1` (-DPNP_DEV); the product library reads no environment variable.
+#ifdef PNP_DEV
+static int dev_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#endif
+
 // Host entry.  N is rounded up to the tile internally (loads clamp, stores mask on Nvalid).
 int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return PNP_ERR_ARG;
+    const bool x3 = g.A_lo || g.B_lo;                      // split-bf16 operands (bf16 pairs), fp32-facing epilogues
+    if (x3) dtype_bf16 = 1;
     const int bk = dtype_bf16 ? 64 : 32;
     if (g.K % bk) return PNP_ERR_ARG;
     if ((g.lda * (dtype_bf16 ? 2 : 4)) % 16 || (g.ldb * (dtype_bf16 ? 2 : 4)) % 16) return PNP_ERR_ARG;
     g.Nvalid = g.N;
+    int variant = 0;
+#ifdef PNP_DEV
+    variant = dev_env("PNP_GEMM_VARIANT", 0);              // 1 / 2 / 3 / 4: generic 256x128 / generic 256x256 / generic 128x128 / wide
+    g.ablate = dev_env("PNP_GEMM_ABLATE", 0);
+    if (dev_env("PNP_GEMM_STAMPS", 0)) {
+        if (!stamp_buf() && hipMalloc(&stamp_buf(), kStampBlocks * 64) != hipSuccess) return PNP_ERR_HIP;
+        g.stamps = stamp_buf();
+    }
+#endif
     // small problems (text side: M = B*L rows) use 64x64 tiles to fill more CUs
     const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const bool small = tiles128 < 192;
+    const bool small = tiles128 < 192 && !x3;
     if (small) {
         // text side (M = B*L rows): 64 x 64 tiles, 4 waves of 32 x 32, 3-slot DMA ring -- the deep
         // prefetch matters more than tile efficiency for these latency-bound launches
         g.N = (g.N + 63) / 64 * 64;
-        static const int small_variant = getenv("PNP_GEMM_SMALL") ? atoi(getenv("PNP_GEMM_SMALL")) : 0;
-        if (small_variant == 1) return dtype_bf16 ? launch_cfg<bf16, 64, 64>(g, s) : launch_cfg<float, 64, 64>(g, s);
-        static const int small_ns = getenv("PNP_GEMM_SMALL_NS") ? atoi(getenv("PNP_GEMM_SMALL_NS")) : 3;
+#ifdef PNP_DEV
+        if (dev_env("PNP_GEMM_SMALL", 0) == 1) return dtype_bf16 ? launch_cfg<bf16, 64, 64>(g, s) : launch_cfg<float, 64, 64>(g, s);
+        const int small_ns = dev_env("PNP_GEMM_SMALL_NS", 3);
         if (dtype_bf16 && small_ns == 4) return launch_big<bf16, 64, 64, 32, 32, 4>(g, s);
         if (dtype_bf16 && small_ns == 6) return launch_big<bf16, 64, 64, 32, 32, 6>(g, s);
+#endif
         return dtype_bf16 ? launch_big<bf16, 64, 64, 32, 32, 3>(g, s) : launch_big<float, 64, 64, 32, 32, 3>(g, s);
     }
     GemmProfile& pf = gemm_profile();
@@ -943,32 +1092,30 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
         }
         (void)hipEventRecord(pf.ev0[pf.used], s);
     }
-    const double fl = 2.0 * g.M * (double)g.N * g.K;
+    const double fl = 2.0 * g.M * (double)g.N * g.K;       // algorithmic FLOPs (the split-bf16 form issues 3x as MFMA work)
     g.N = (g.N + 127) / 128 * 128;
-    // Tile choice (in-kernel clock stamps, PNP_GEMM_STAMPS=1, tools/gemm_stamps.py):
+    // Tile choice (in-kernel clock stamps, tools/gemm_stamps.py on a DEV build):
     //   bf16 ViT-block epilogues (bias -> bf16 | bias+GELU -> bf16 | bias+residual -> f32), >= 128 tiles:
     //       gemm_nt_wide_kernel, 256 x 256, 32x32x16 MFMA; main loop ~2350 clk per 64-deep slab against
     //       2048 MFMA clk, epilogue staged through LDS (full-line stores)
+    //   split-bf16 operands       : always the wide kernel (its X3 form)
     //   other bf16 with K >= 2048 : generic 256 x 256 (16x16x32 MFMA, simple ring)
     //   otherwise                 : generic 128 x 128, two workgroups per CU
-    // PNP_GEMM_VARIANT=1 / 2 / 3 / 4 force generic 256x128 / generic 256x256 / generic 128x128 / wide.
-    static const int variant = getenv("PNP_GEMM_VARIANT") ? atoi(getenv("PNP_GEMM_VARIANT")) : 0;
-    static const int ablate = getenv("PNP_GEMM_ABLATE") ? atoi(getenv("PNP_GEMM_ABLATE")) : 0;
-    g.ablate = ablate;
-    static const int want_stamps = getenv("PNP_GEMM_STAMPS") ? atoi(getenv("PNP_GEMM_STAMPS")) : 0;
-    if (want_stamps) {
-        if (!stamp_buf() && hipMalloc(&stamp_buf(), kStampBlocks * 64) != hipSuccess) return PNP_ERR_HIP;
-        g.stamps = stamp_buf();
-    }
     int r;
     const bool big_k = g.K >= 2048 && g.Nvalid >= 512;
     const int wide = dtype_bf16 ? wide_epilogue_kind(g) : -1;
     const long tiles256 = (long)((g.M + 255) / 256) * ((g.Nvalid + 255) / 256);
-    if (wide >= 0 && (variant == 4 || (variant == 0 && tiles256 >= 128))) {
+    if (x3) {
+        if (wide < 0) return PNP_ERR_ARG;
         g.N = (g.Nvalid + 255) / 256 * 256;
-        r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16>(g, s)
-            : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16>(g, s)
-            : wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32>(g, s) : launch_wide<WIDE_TOKCOLS_BF16>(g, s);
+        r = wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32, true>(g, s)
+            : wide == WIDE_BIAS_F32 ? launch_wide<WIDE_BIAS_F32, true>(g, s)
+            : wide == WIDE_GELU_SPLIT ? launch_wide<WIDE_GELU_SPLIT, true>(g, s) : launch_wide<WIDE_TOKCOLS_F32, true>(g, s);
+    } else if (wide >= 0 && (variant == 4 || (variant == 0 && tiles256 >= 128))) {
+        g.N = (g.Nvalid + 255) / 256 * 256;
+        r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16, false>(g, s)
+            : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16, false>(g, s)
+            : wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32, false>(g, s) : launch_wide<WIDE_TOKCOLS_BF16, false>(g, s);
     } else if (variant == 1) {
         r = dtype_bf16 ? launch_big<bf16, 256, 128, 64, 64, 3>(g, s) : launch_big<float, 256, 128, 64, 64, 3>(g, s);
     } else if (dtype_bf16 && (variant == 2 || (variant == 0 && big_k))) {

@@ -43,9 +43,9 @@ struct CrfLattice {
 int patchify(int bf, const float* img, const uint8_t* dropped, void* out, int B, int S, int P, hipStream_t s);
 int cls_rows(const float* cls, const float* pos, float* x, int B, int N, int D, hipStream_t s);
 int layernorm(int bf, const float* x, const float* w, const float* b, float eps, int rows, int D, float* y, void* yt,
-              float* xhat, float* rstd, hipStream_t s);
+              float* xhat, float* rstd, hipStream_t s, void* yt_lo = nullptr);
 int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
-                  int H, int N, float scale, hipStream_t s);
+                  int H, int N, float scale, hipStream_t s, void* ctx_lo = nullptr);
 
 // text_kernels.hip
 int text_embed(const int64_t* ids, int ld_ids, const float* word, const float* pos, float* out, int B, int L, int H,
@@ -61,6 +61,7 @@ int layernorm_bwd(int bf, const float* dy, const float* w, const float* xhat, co
 int itm_head(const float* hlast, const float* w, const float* bias, float* logits, int B, int L, int H, hipStream_t s);
 int itm_grad_seed(const float* w, float* dh, int B, int L, int H, hipStream_t s);
 int cast_f32(int bf, const float* in, void* out, size_t n, hipStream_t s);
+int split_f32(const float* in, void* hi, void* lo, size_t n, hipStream_t s);     // x ~ hi + lo, both bf16 (round to nearest even)
 
 // pipeline_kernels.hip
 int gradcam_gather(const float* P, const float* dP, const int64_t* mask, int ld_mask, float* out, int B, int nheads,

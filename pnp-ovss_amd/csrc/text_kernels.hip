@@ -472,6 +472,16 @@ __global__ void cast_kernel(const float* __restrict__ in, T* __restrict__ out, s
     if (i < n) out[i] = from_f32<T>(in[i]);
 }
 
+__global__ void split_kernel(const float* __restrict__ in, bf16* __restrict__ hi, bf16* __restrict__ lo, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = in[i];
+        const bf16 h = (bf16)v;
+        hi[i] = h;
+        lo[i] = (bf16)(v - (float)h);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 static inline int ok() { return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP; }
 
@@ -582,6 +592,12 @@ int cast_f32(int bf, const float* in, void* out, size_t n, hipStream_t s) {
     const unsigned nb = (unsigned)((n + 255) / 256);
     if (bf) hipLaunchKernelGGL((cast_kernel<bf16>), dim3(nb), dim3(256), 0, s, in, (bf16*)out, n);
     else hipLaunchKernelGGL((cast_kernel<float>), dim3(nb), dim3(256), 0, s, in, (float*)out, n);
+    return ok();
+}
+
+int split_f32(const float* in, void* hi, void* lo, size_t n, hipStream_t s) {
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(split_kernel, dim3(nb), dim3(256), 0, s, in, (bf16*)hi, (bf16*)lo, n);
     return ok();
 }
 

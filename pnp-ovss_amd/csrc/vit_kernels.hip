@@ -51,7 +51,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ b, float eps, int rows, int D,
                                                         float* __restrict__ y, T* __restrict__ yt,
-                                                        float* __restrict__ xhat, float* __restrict__ rstd_out) {
+                                                        float* __restrict__ xhat, float* __restrict__ rstd_out,
+                                                        bf16* __restrict__ yt_lo = nullptr) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -99,6 +100,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if constexpr (sizeof(T) == 2) {          // one 8-byte store per lane: 512 contiguous bytes per wave
                 const bf16x4 pk = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
                 *reinterpret_cast<bf16x4*>(p) = pk;
+                if (yt_lo) {                     // split-bf16 operand pair: lo = bf16(o - hi)
+                    const bf16x4 pl = {(bf16)(o[0] - (float)pk[0]), (bf16)(o[1] - (float)pk[1]), (bf16)(o[2] - (float)pk[2]),
+                                       (bf16)(o[3] - (float)pk[3])};
+                    *reinterpret_cast<bf16x4*>(yt_lo + (size_t)row * D + c * 4) = pl;
+                }
             } else {
                 *reinterpret_cast<f32x4*>(p) = o;
             }
@@ -118,7 +124,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qk, int ld_qk, int D,
                                                        const T* __restrict__ vt, int ld_vt, int Npad,
-                                                       T* __restrict__ ctx, int N, float scale) {
+                                                       T* __restrict__ ctx, int N, float scale,
+                                                       bf16* __restrict__ ctx_hi = nullptr, bf16* __restrict__ ctx_lo = nullptr) {
     constexpr int ROWB = 64 * Elem<T>::kBytes;
     constexpr int CPR = ROWB / 16;                 // 16-byte chunks per LDS row
     constexpr int CPT = 64 * CPR / 256;            // chunks per thread per tile
@@ -235,7 +242,16 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const T* __restrict__ qk,
                 *reinterpret_cast<bf16x4*>(o + dt * 16) = pk;
             } else {
                 f32x4 ov = acc_o[dt] * inv;
-                *reinterpret_cast<f32x4*>(o + dt * 16) = ov;
+                if (ctx_hi) {                    // split-bf16 mode: the output feeds the proj GEMM as a (hi, lo) bf16 pair
+                    const size_t off = (row0 + qrow) * D + h * 64 + q * 4 + dt * 16;
+                    const bf16x4 ph = {(bf16)ov[0], (bf16)ov[1], (bf16)ov[2], (bf16)ov[3]};
+                    const bf16x4 pl = {(bf16)(ov[0] - (float)ph[0]), (bf16)(ov[1] - (float)ph[1]), (bf16)(ov[2] - (float)ph[2]),
+                                       (bf16)(ov[3] - (float)ph[3])};
+                    *reinterpret_cast<bf16x4*>(ctx_hi + off) = ph;
+                    *reinterpret_cast<bf16x4*>(ctx_lo + off) = pl;
+                } else {
+                    *reinterpret_cast<f32x4*>(o + dt * 16) = ov;
+                }
             }
         }
     }
@@ -399,28 +415,23 @@ __global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------ host
-template <typename T>
-static int vit_attn_t(const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
-                      int H, int N, float scale, hipStream_t s) {
-    dim3 grid((N + 63) / 64, H, B);
-    hipLaunchKernelGGL((vit_attn_kernel<T>), grid, dim3(256), 0, s, (const T*)qk, ld_qk, D, (const T*)vt, ld_vt,
-                       Npad, (T*)ctx, N, scale);
-    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
-}
-
+// ctx_lo != nullptr (fp32 kernel only): the output is written as a split-bf16 pair (ctx = hi, ctx_lo = lo)
 int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
-                  int H, int N, float scale, hipStream_t s) {
+                  int H, int N, float scale, hipStream_t s, void* ctx_lo) {
     if (D != H * 64 || Npad % 64 || Npad < N) return PNP_ERR_ARG;
     if (bf) {       // bf16: `vt` is V in the NATURAL layout [B*N, ld_vt] (the fused q|k|v rows), transposed on the LDS read
+        if (ctx_lo) return PNP_ERR_ARG;
         const int nqw = (N + 31) / 32;                          // 32-query waves per (image, head)
-        static const int max_wpb = getenv("PNP_ATTN_WPB") ? atoi(getenv("PNP_ATTN_WPB")) : 8;
+        const int max_wpb = 8;
         const int nblk = (nqw + max_wpb - 1) / max_wpb, wpb = (nqw + nblk - 1) / nblk;
         hipLaunchKernelGGL(vit_attn32_kernel, dim3(nblk, H, B), dim3(wpb * 64), 0, s, (const bf16*)qk, ld_qk, D,
                            (const bf16*)vt, ld_vt, Npad, (bf16*)ctx, N, scale, nqw);
         return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
     }
-    return bf ? vit_attn_t<bf16>(qk, ld_qk, D, vt, ld_vt, Npad, ctx, B, H, N, scale, s)
-              : vit_attn_t<float>(qk, ld_qk, D, vt, ld_vt, Npad, ctx, B, H, N, scale, s);
+    dim3 grid((N + 63) / 64, H, B);
+    hipLaunchKernelGGL((vit_attn_kernel<float>), grid, dim3(256), 0, s, (const float*)qk, ld_qk, D, (const float*)vt, ld_vt,
+                       Npad, ctx_lo ? nullptr : (float*)ctx, N, scale, ctx_lo ? (bf16*)ctx : nullptr, (bf16*)ctx_lo);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
 int patchify(int bf, const float* img, const uint8_t* dropped, void* out, int B, int S, int P, hipStream_t s) {
@@ -436,12 +447,14 @@ int cls_rows(const float* cls, const float* pos, float* x, int B, int N, int D, 
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
+// yt_lo != nullptr (with bf != 0): yt / yt_lo receive the split-bf16 pair of the output
 int layernorm(int bf, const float* x, const float* w, const float* b, float eps, int rows, int D, float* y, void* yt,
-              float* xhat, float* rstd, hipStream_t s) {
+              float* xhat, float* rstd, hipStream_t s, void* yt_lo) {
     if (D > 1024 || D % 4) return PNP_ERR_ARG;
+    if (yt_lo && !bf) return PNP_ERR_ARG;
     const int nb = (rows + 3) / 4;
-    if (bf) hipLaunchKernelGGL((layernorm_kernel<bf16>), dim3(nb), dim3(256), 0, s, x, w, b, eps, rows, D, y, (bf16*)yt, xhat, rstd);
-    else hipLaunchKernelGGL((layernorm_kernel<float>), dim3(nb), dim3(256), 0, s, x, w, b, eps, rows, D, y, (float*)yt, xhat, rstd);
+    if (bf) hipLaunchKernelGGL((layernorm_kernel<bf16>), dim3(nb), dim3(256), 0, s, x, w, b, eps, rows, D, y, (bf16*)yt, xhat, rstd, (bf16*)yt_lo);
+    else hipLaunchKernelGGL((layernorm_kernel<float>), dim3(nb), dim3(256), 0, s, x, w, b, eps, rows, D, y, (float*)yt, xhat, rstd, (bf16*)nullptr);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 

@@ -58,6 +58,9 @@ def load_library():
         "pnp_cross_kv": (i32, [vp, i32, vp]),
         "pnp_text_forward_xattn": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
         "pnp_xattn_grad": (i32, [vp, i32, i32, vp]),
+        "pnp_xattn_grad_layer": (i32, [vp, i32, i32, i32, vp]),
+        "pnp_compute_gradcam_layer": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+        "pnp_drop_loop_layer": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
         "pnp_gradcam_gather": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
         "pnp_compute_gradcam": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]),
         "pnp_drop_step": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
@@ -82,6 +85,8 @@ def load_library():
         "pnp_preprocess_images": (i32, [vp, vp, i32, i32, i32, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
         "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
         "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
+        "pnp_op_split": (i32, [vp, vp, vp, i64, vp]),
+        "pnp_op_gemm_x3": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
         "pnp_dbg_gemm_stamps": (i32, [vp, i32]),
         "pnp_op_xattn": (i32, [i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     }
@@ -98,7 +103,8 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
             "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images",
-            "pnp_cross_kv", "pnp_profile_read_stage"]
+            "pnp_cross_kv", "pnp_profile_read_stage", "pnp_op_split", "pnp_op_gemm_x3",
+            "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer"]
 
 
 class _DevView:
@@ -221,18 +227,27 @@ def gaussian_taps(H, W, scale=0.05, truncate=4.0):
 class Engine:
     """One libpnp_hip engine on one GPU."""
 
-    def __init__(self, cfg, max_batch, max_text_len=64, stash_layer=7, bf16=True, device=0):
+    MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
+
+    def __init__(self, cfg, max_batch, max_text_len=64, stash_layer=7, bf16=True, device=0, mode=None):
+        """mode: "f32" (the reference's arithmetic), "bf16" (throughput), "bf16x3" (split-bf16: fp32-class results on the
+        bf16 MFMA); `bf16=True/False` is the older spelling of "bf16" / "f32"."""
         if not torch.cuda.is_available():
             raise RuntimeError("pnp_ovss.hip.Engine needs a HIP device (no CPU fallback)")
         self.lib = load_library()
         self.cfg = cfg
         self.device = torch.device("cuda", device)
-        self.bf16 = bool(bf16)
+        if mode is None:
+            mode = "bf16" if bf16 else "f32"
+        if mode not in self.MODES:
+            raise ValueError(f"unknown compute mode {mode!r}")
+        self.mode = mode
+        self.bf16 = mode == "bf16"
         self.max_batch, self.max_text_len, self.stash_layer = max_batch, max_text_len, stash_layer
         c = PnpConfig(cfg.img_size, cfg.patch, cfg.vit_dim, cfg.vit_depth, cfg.vit_heads, cfg.vit_mlp_ratio,
                       cfg.vit_ln_eps, cfg.txt_hidden, cfg.txt_layers, cfg.txt_heads, cfg.txt_inter, cfg.txt_ln_eps,
                       cfg.vocab, cfg.max_pos, cfg.enc_token_id, max_batch, max_text_len, stash_layer,
-                      1 if bf16 else 0, device)
+                      self.MODES[mode], device)
         self._c = c
         self.h = C.c_void_p()
         torch.cuda.set_device(device)
@@ -295,8 +310,10 @@ class Engine:
                   "pnp_text_forward_xattn")
         return logits
 
-    def xattn_grad(self, B, L):
-        self._chk(self.lib.pnp_xattn_grad(self.h, B, L, _stream()), "pnp_xattn_grad")
+    def xattn_grad(self, B, L, layer=None):
+        """Backward down to `layer` (default: stash_layer); gradcam_gather / buffer("P") / buffer("dP") then refer to it."""
+        layer = self.stash_layer if layer is None else int(layer)
+        self._chk(self.lib.pnp_xattn_grad_layer(self.h, B, L, layer, _stream()), "pnp_xattn_grad_layer")
 
     def gradcam_gather(self, mask, L, head):
         B, ld = mask.shape
@@ -305,22 +322,24 @@ class Engine:
                   "pnp_gradcam_gather")
         return out
 
-    def compute_gradcam(self, images, ids, mask, L, head, dropped=None):
+    def compute_gradcam(self, images, ids, mask, L, head, dropped=None, layer=None):
         B, ld = ids.shape
         out = torch.empty(B, L - 1, self.grid, self.grid, device=self.device, dtype=torch.float32)
         logits = torch.empty(B, 2, device=self.device, dtype=torch.float32)
-        self._chk(self.lib.pnp_compute_gradcam(self.h, _ptr(images), _ptr(dropped), _ptr(ids), _ptr(mask), ld, B, L,
-                                               head, _ptr(out), _ptr(logits), _stream()), "pnp_compute_gradcam")
+        layer = self.stash_layer if layer is None else int(layer)
+        self._chk(self.lib.pnp_compute_gradcam_layer(self.h, _ptr(images), _ptr(dropped), _ptr(ids), _ptr(mask), ld, B, L,
+                                                     layer, head, _ptr(out), _ptr(logits), _stream()), "pnp_compute_gradcam_layer")
         return out, logits
 
-    def drop_loop(self, images, ids, mask, L, head, drop_iter, npick=10):
+    def drop_loop(self, images, ids, mask, L, head, drop_iter, npick=10, layer=None):
         B, ld = ids.shape
+        layer = self.stash_layer if layer is None else int(layer)
         g0 = torch.empty(B, L - 1, self.grid, self.grid, device=self.device, dtype=torch.float32)
         agg = torch.empty_like(g0) if drop_iter > 1 else None
         picks = torch.full((B, max(drop_iter, 1) * npick), -1, device=self.device, dtype=torch.int32)
         logits = torch.empty(B, 2, device=self.device, dtype=torch.float32)
-        self._chk(self.lib.pnp_drop_loop(self.h, _ptr(images), _ptr(ids), _ptr(mask), ld, B, L, head, drop_iter, npick,
-                                         _ptr(g0), _ptr(agg), _ptr(picks), _ptr(logits), _stream()), "pnp_drop_loop")
+        self._chk(self.lib.pnp_drop_loop_layer(self.h, _ptr(images), _ptr(ids), _ptr(mask), ld, B, L, layer, head, drop_iter,
+                                               npick, _ptr(g0), _ptr(agg), _ptr(picks), _ptr(logits), _stream()), "pnp_drop_loop_layer")
         return g0, agg, picks, logits
 
     # ------------------------------------------------------------------ post-process
