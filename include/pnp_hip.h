@@ -54,6 +54,7 @@ int pnp_create(const pnp_config* cfg, pnp_engine** out);
 void pnp_destroy(pnp_engine* e);
 const char* pnp_last_error(const pnp_engine* e);          /* valid until the next call on e */
 size_t pnp_workspace_bytes(const pnp_config* cfg);         /* device bytes pnp_create will allocate */
+size_t pnp_allocated_bytes(const pnp_engine* e);           /* device bytes the engine holds now (create + post_reserve + weights) */
 
 /* Weights in: replaces BaseModel.load_checkpoint + load_state_dict (B/base_model.py:86-125).
  * `name` is the reference state-dict key ("visual_encoder.blocks.3.attn.qkv.weight", ...), data is

@@ -58,10 +58,11 @@ def get_args_parser():
     p.add_argument("--postprocess", default=None, type=str, help="blur or crf or blur+crf")
     p.add_argument("--threshold", default=None, type=float)
     # additions
-    p.add_argument("--dtype", default="f32", choices=["bf16", "f32"],
-                   help="f32 (default): the reference's arithmetic -- same patch picks and label maps as the reference's own "
-                        "fp32 run; bf16: 3.8x the throughput, but ~1%% error on image_embeds moves near-tie patch picks, "
-                        "so ~5-10%% of label pixels differ (tests/test_hip_parity.py::test_bf16_vs_f32_divergence_is_bounded)")
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16x3", "bf16"],
+                   help="f32 (default): the reference's arithmetic; bf16x3: split-bf16 -- fp32-class products on the bf16 MFMA, "
+                        "same patch picks as f32 in every test, 2x its throughput; bf16: 3.8x the throughput of f32, but ~1%% error "
+                        "on image_embeds moves near-tie patch picks, so ~5-10%% of label pixels differ "
+                        "(tests/test_hip_parity.py::test_bf16_vs_f32_divergence_is_bounded)")
     p.add_argument("--crf_chunk", default=0, type=int, help="images per DenseCRF launch group (0 = the whole batch)")
     p.add_argument("--checkpoint", default=None, help="BLIP ITM-large checkpoint (.pth); default: seeded synthetic weights")
     p.add_argument("--vocab", default=None, help="bert-base-uncased vocab.txt")
@@ -90,16 +91,23 @@ def main(rank, world_size, args):
         raise SystemExit('--del_patch_num must contain "sort_thresh" (reference :645-647)')
     ds = make_dataset(args, rank, world_size)
     from lavis.models import load_model_and_preprocess
+    stash_layer = args.max_att_block_num - 1
+    if args.ensemble_blocks is not None and "saveall" in args.ensemble_blocks:
+        stash_layer = int(args.layer) - 1 if args.layer else 0         # lowest layer of the sweep (default: all 12)
     model, vis_processors, text_processors = load_model_and_preprocess(
         "blip_image_text_matching", "large", device=rank, is_eval=True, img_size=args.img_size,
-        max_batch=args.batch_size, stash_layer=args.max_att_block_num - 1, bf16=(args.dtype == "bf16"),
+        max_batch=args.batch_size, stash_layer=stash_layer, mode=args.dtype,
         checkpoint=args.checkpoint, vocab=args.vocab, max_text_len=ds.max_text_len)
     coco = args.data_type in ("coco_object", "coco_stuff")
     n_class = host.coco_n_class(args.data_type) if coco else len(ds.cats) + 1        # PnPc.py:597-600 / PnP.py:1115
     seg = Segmenter(model, args.data_type if args.data_type != "synthetic" else "voc", n_class, threshold=args.threshold,
                     postprocess=args.postprocess, max_pixels_per_image=ds.max_pixels, max_channels=ds.max_channels,
                     crf_chunk=args.crf_chunk, class_ids=ds.class_ids)
-    layer, head = args.max_att_block_num, int(args.prune_att_head)
+    # --ensemble_blocks saveall (reference get_grad_cam_labelascaption: `for block in range(0, 12): for head in
+    # range(0, 12)` around save_img_union_attention): one evaluation per (text layer, head), histograms saved under
+    # that pair's file name; the model keeps maps from the lowest swept layer up (stash_layer), one forward per pair
+    sweep = args.ensemble_blocks is not None and "saveall" in args.ensemble_blocks
+    pairs = [(b + 1, h) for b in range(stash_layer, 12) for h in range(12)] if sweep else [(args.max_att_block_num, int(args.prune_att_head))]
     for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
         Path(f"{args.save_path}/{d}/").mkdir(parents=True, exist_ok=True)
     n_img = 0
@@ -112,21 +120,24 @@ def main(rank, world_size, args):
             b, names, cap = ds.predicted_classes(img_id)
             best.append(b)
             caps.append(cap)
-        seg.hist_1drop.zero_()
-        seg.hist_ndrop.zero_()
-        l1, ln = seg.run(args, batch["imgs"], caps, best, batch["org_images"], batch["label_trues"], run_1drop=True)
-        torch.cuda.synchronize()
-        h1 = seg.hist_1drop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
-        hn = seg.hist_ndrop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
-        first = batch["img_ids"][0]
-        if l1 is not None:                      # the COCO driver skips the 1-drop branch when drop_iter >= 3 (PnPc.py:420,633)
-            np.save(f"{args.save_path}/hist_withfiltered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", h1)
-        if ln is not None:
-            np.save(f"{args.save_path}/all_drop_hist_with_filtered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", hn)
-        print(batch["img_ids"][:3], "miou filtered_caption", host.scores_from_hist(h1)["Mean IoU"] if l1 is not None else None,
-              "miou all_drop", host.scores_from_hist(hn)["Mean IoU"] if ln is not None else None, flush=True)
+        for layer, head in pairs:
+            pargs = argparse.Namespace(**{**vars(args), "max_att_block_num": layer, "prune_att_head": str(head)})
+            seg.hist_1drop.zero_()
+            seg.hist_ndrop.zero_()
+            l1, ln = seg.run(pargs, batch["imgs"], caps, best, batch["org_images"], batch["label_trues"], run_1drop=True)
+            torch.cuda.synchronize()
+            h1 = seg.hist_1drop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
+            hn = seg.hist_ndrop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
+            first = batch["img_ids"][0]
+            if l1 is not None:                  # the COCO driver skips the 1-drop branch when drop_iter >= 3 (PnPc.py:420,633)
+                np.save(f"{args.save_path}/hist_withfiltered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", h1)
+            if ln is not None:
+                np.save(f"{args.save_path}/all_drop_hist_with_filtered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", hn)
+            print(batch["img_ids"][:3], f"layer {layer} head {head}", "miou filtered_caption",
+                  host.scores_from_hist(h1)["Mean IoU"] if l1 is not None else None,
+                  "miou all_drop", host.scores_from_hist(hn)["Mean IoU"] if ln is not None else None, flush=True)
         n_img += len(batch["img_ids"])
-        ds.total_hist += hn if ln is not None else h1
+        ds.total_hist += hn if ln is not None else h1           # summary line: the last (layer, head) of the sweep
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_loop
     total = torch.from_numpy(ds.total_hist).to(torch.device("cuda", rank))

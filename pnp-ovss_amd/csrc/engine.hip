@@ -1015,11 +1015,15 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
     const size_t Kp = (K + 3) / 4 * 4;
     p.maxKp = (int)Kp;
     // the paired 1-drop | N-drop run keeps two channel groups per row: size the CRF arrays for it unless that would
-    // take more than 96 GB (many classes x large images); pnp_postprocess_pair then runs the two branches one after the other
+    // take more than a third of the free device memory (many classes x large images); pnp_postprocess_pair then runs
+    // the two branches one after the other
     {
         const size_t chunk_pix0 = (size_t)std::min<int64_t>((int64_t)(crf_chunk > 0 ? crf_chunk : B) * max_pixels_per_image, max_total_pixels);
         const size_t single = (2 * TP * Kp + 2 * chunk_pix0 * 6 * Kp + 2 * chunk_pix0 * 3 * Kp) * sizeof(float);
-        p.groups_cap = 2 * single <= ((size_t)96 << 30) ? 2 : 1;
+        // ... of what the device has free right now (the rest of this function needs about as much again for maps and lattices)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)96 << 30;
+        p.groups_cap = 2 * single <= free_b / 3 ? 2 : 1;
     }
     const size_t G2 = (size_t)p.groups_cap;
     KCHK(e, dalloc(e, &p.unary, TP * Kp * G2));
@@ -1196,7 +1200,11 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
         int err = 0;
         HIPCHK(e, hipMemcpyAsync(&err, p.range_err, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(e, hipStreamSynchronize(s));
-        if (err) return fail(e, PNP_ERR_ARG, "lattice key out of packing range (image too large for the 64-bit key)");
+        if (err) {                           // leave no stale state behind: the next prepare rebuilds both lattices
+            p.gauss_sig.clear();
+            (void)hipMemsetAsync(p.range_err, 0, 4, s);
+            return fail(e, PNP_ERR_ARG, "lattice key out of packing range (image too large for the 64-bit key)");
+        }
         p.gauss_sig = sig;
         p.has_crf = true;
     }
@@ -1401,6 +1409,8 @@ extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, siz
     }
     return fail(e, PNP_ERR_ARG, "unknown buffer %s", name);
 }
+
+extern "C" size_t pnp_allocated_bytes(const pnp_engine* e) { return e ? e->alloc_bytes : 0; }
 
 extern "C" int pnp_profile_enable(pnp_engine* e, int32_t on) {
     if (!e) return PNP_ERR_ARG;

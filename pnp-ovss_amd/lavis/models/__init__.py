@@ -22,9 +22,9 @@ class BlipImageEvalProcessor:
 
 
 class BlipCaptionProcessor:
-    """blip_processors.py:28-68 (prompt + whitespace clean-up, 50-word cap)."""
+    """blip_processors.py:28-68 (prompt + whitespace clean-up; the file's default cap is 500 words, :30)."""
 
-    def __init__(self, prompt="", max_words=50):
+    def __init__(self, prompt="", max_words=500):
         self.prompt, self.max_words = prompt, max_words
 
     def __call__(self, caption):

@@ -52,6 +52,7 @@ def load_library():
         "pnp_destroy": (None, [vp]),
         "pnp_last_error": (C.c_char_p, [vp]),
         "pnp_workspace_bytes": (C.c_size_t, [C.POINTER(PnpConfig)]),
+        "pnp_allocated_bytes": (C.c_size_t, [vp]),
         "pnp_load_weight": (i32, [vp, C.c_char_p, vp, C.POINTER(i64), i32, i32]),
         "pnp_finalize_weights": (i32, [vp]),
         "pnp_vit_forward": (i32, [vp, vp, vp, i32, vp]),
@@ -104,7 +105,7 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
             "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images",
             "pnp_cross_kv", "pnp_profile_read_stage", "pnp_op_split", "pnp_op_gemm_x3",
-            "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer"]
+            "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer", "pnp_allocated_bytes"]
 
 
 class _DevView:
@@ -277,6 +278,9 @@ class Engine:
     @property
     def grid(self):
         return self.cfg.grid
+
+    def allocated_bytes(self):
+        return int(self.lib.pnp_allocated_bytes(self.h))
 
     # ------------------------------------------------------------------ weights
     def load_state_dict(self, sd, finalize=True):

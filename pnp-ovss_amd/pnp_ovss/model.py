@@ -34,9 +34,11 @@ class _CrossSelf:
         self.save_attention = False
 
     def _check(self):
-        if self._i != self._m.engine.stash_layer:
-            raise RuntimeError(f"the engine keeps cross-attention maps for text layer {self._m.engine.stash_layer} only "
+        eng = self._m.engine
+        if self._i < eng.stash_layer:
+            raise RuntimeError(f"the engine keeps cross-attention maps for text layers >= {eng.stash_layer} "
                                f"(max_att_block_num - 1); re-create the model with stash_layer={self._i}")
+        self._m._grad_to(self._i)
 
     def get_attention_map(self):
         self._check()
@@ -75,6 +77,7 @@ class BlipITM:
         self.visual_encoder.vision_width = cfg.vit_dim
         self.module = self                                         # DDP-wrapper attribute the driver dereferences
         self._last = None
+        self._grad_layer = None
 
     # nn.Module-ish no-ops the driver calls
     def eval(self):
@@ -94,6 +97,14 @@ class BlipITM:
         return self.tokenizer(captions, padding="longest", truncation=True, max_length=self.max_txt_len,
                               return_tensors="pt")
 
+    def _grad_to(self, layer):
+        """Make P / dP / gradcam_gather refer to `layer`: the analytic backward re-run down to it when the last one
+        stopped elsewhere (activations of the forward are still in the engine)."""
+        if self._grad_layer != layer:
+            B, L = self._last
+            self.engine.xattn_grad(B, L, layer)
+            self._grad_layer = layer
+
     def _stash(self, name):
         B, L = self._last
         N, nst = self.cfg.n_img_tokens, (self.cfg.n_img_tokens + 63) // 64 * 64
@@ -110,6 +121,7 @@ class BlipITM:
         self.engine.vit_forward(image)
         logits = self.engine.text_forward(text.input_ids.contiguous(), text.attention_mask.contiguous(), L)
         self._last = (image.shape[0], L)
+        self._grad_layer = None
         return logits
 
 
@@ -128,17 +140,23 @@ class _LazyHeads:
 
 class _LazyBlocks:
     """gradcam_blocklist[layer][head]: materialised on demand (the reference builds all 144 maps and
-    the driver reads one, PnP.py:619-621)."""
+    the driver reads one, PnP.py:619-621).  Layers >= the engine's stash_layer are available -- all 12 x 12 with
+    stash_layer = 0 (the layer / head sweep the full return value exists for); a layer other than the last one
+    asked for costs one more analytic backward (text layers only), no second forward."""
 
     def __init__(self, model, mask, L):
         self._m, self._mask, self._L = model, mask, L
 
     def __getitem__(self, layer):
         eng = self._m.engine
-        if layer != eng.stash_layer:
-            raise RuntimeError(f"GradCAM maps are kept for text layer {eng.stash_layer} only; "
+        if layer < eng.stash_layer or layer >= self._m.cfg.txt_layers:
+            raise RuntimeError(f"GradCAM maps are kept for text layers >= {eng.stash_layer}; "
                                f"re-create the model with stash_layer={layer}")
-        return _LazyHeads(lambda h: eng.gradcam_gather(self._mask, self._L, h).cpu())
+
+        def head_map(h):
+            self._m._grad_to(layer)
+            return eng.gradcam_gather(self._mask, self._L, h).cpu()
+        return _LazyHeads(head_map)
 
     def __len__(self):
         return 12
@@ -156,6 +174,7 @@ def compute_gradcam_ensemble(args, model, visual_input, text_input, tokenized_te
     logits = eng.text_forward(text.input_ids.contiguous(), text.attention_mask.contiguous(), L)
     eng.xattn_grad(B, L)
     m._last = (B, L)
+    m._grad_layer = eng.stash_layer
     mask = tokenized_text.attention_mask.to(m.device).contiguous()          # the caller's 500-padded mask (:415-416)
     return _LazyBlocks(m, mask, L), [], logits
 
@@ -168,8 +187,10 @@ def drop_loop(args, model, txt_tokens, imgs_in, caption_list):
     L = text.input_ids.shape[1]
     mask = txt_tokens.attention_mask.to(m.device).contiguous()
     ids = txt_tokens.input_ids.to(m.device).contiguous()
-    g0, agg, picks, _ = m.engine.drop_loop(image, ids, mask, L, int(args.prune_att_head), int(args.drop_iter))
+    layer = int(args.max_att_block_num) - 1 if getattr(args, "max_att_block_num", None) is not None else m.engine.stash_layer
+    g0, agg, picks, _ = m.engine.drop_loop(image, ids, mask, L, int(args.prune_att_head), int(args.drop_iter), layer=layer)
     m._last = (image.shape[0], L)
+    m._grad_layer = layer
     return g0, agg
 
 
@@ -211,7 +232,7 @@ def merge_checkpoint(cfg, ckpt_state, init_state):
 
 
 def build_model(model_type="large", img_size=336, device=0, max_batch=35, max_text_len=64, stash_layer=7, bf16=True,
-                checkpoint=None, vocab=None, seed=0, cfg=None):
+                checkpoint=None, vocab=None, seed=0, cfg=None, mode=None):
     """from_config + load_checkpoint (blip_image_text_matching.py:297-314, base_model.py:86-125)."""
     if cfg is None:
         if model_type != "large":
@@ -220,7 +241,7 @@ def build_model(model_type="large", img_size=336, device=0, max_batch=35, max_te
     checkpoint = checkpoint or os.environ.get("PNP_OVSS_CHECKPOINT")
     vocab = vocab or os.environ.get("PNP_OVSS_VOCAB")
     dev = device if isinstance(device, int) else (torch.device(device).index or 0)
-    eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len, stash_layer=stash_layer, bf16=bf16, device=dev)
+    eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len, stash_layer=stash_layer, bf16=bf16, device=dev, mode=mode)
     init = synth.synth_state_dict(cfg, seed)                      # stands in for the module's initialisation
     if checkpoint:
         sd = torch.load(checkpoint, map_location="cpu")

@@ -98,6 +98,32 @@ def gen_gradcam_large():
     print("gradcam_large: map", g[7][9].shape, "max", g[7][9].max().item())
 
 
+def gen_gradcam_large_768():
+    """BASELINE config 5 geometry at full model size: BLIP-ITM-large at img_size 768 (48 x 48 patches, 2305 image tokens),
+    B = 1, an ADE20K-sized prompt (40 classes, L = 45): the selected map [7][9], one more (layer, head), logits."""
+    cfg = C.blip_itm_large(768)
+    m, itm, tok = _model(cfg, seed=0)
+    _, imgs = synth.synth_images(1, 768, seed=4321)
+    ids, mask = synth.synth_tokens(cfg, [40], seed=4321)
+
+    class Fixed:
+        enc_token_id = cfg.enc_token_id
+        pad_token_id = 0
+
+        def __call__(self, caps, padding="longest", max_length=None, **kw):
+            from pnp_ovss.tokenizer import Encoding
+            L = max_length if padding == "max_length" else int(mask.sum(1).max())
+            return Encoding(torch.from_numpy(ids[:, :L]), torch.from_numpy(mask[:, :L]))
+    m.tokenizer = Fixed()
+    tok500 = m.tokenizer(["x"], padding="max_length", max_length=500)
+    args = argparse.Namespace(img_size=768)
+    g, _, out = itm.compute_gradcam_ensemble(args, m, torch.from_numpy(imgs), ["x"], tok500)
+    np.savez_compressed(os.path.join(HERE, "gradcam_large_768.npz"), cfg=json.dumps(cfg.as_dict()), weight_seed=0,
+                        image_seed=4321, token_seed=4321, n_classes=40, map_7_9=g[7][9].numpy().astype(np.float32),
+                        map_11_3=g[11][3].numpy().astype(np.float32), logits=out.detach().numpy())
+    print("gradcam_large_768: map", g[7][9].shape, "max", g[7][9].max().item())
+
+
 def _driver_ns(itm, extra=None):
     from pathlib import Path
     import scipy.ndimage as filters
@@ -622,7 +648,7 @@ def gen_preprocess_cases():
     print("preprocess_cases:", len(cases), "cases, Pillow", PIL.__version__)
 
 
-GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, droploop_small=gen_droploop_small,
+GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, gradcam_large_768=gen_gradcam_large_768, droploop_small=gen_droploop_small,
             merge_tokens=gen_merge_tokens, pipeline_voc=gen_pipeline_voc, pipeline_psc=gen_pipeline_psc,
             pipeline_coco_object=gen_pipeline_coco_object, pipeline_coco_stuff=gen_pipeline_coco_stuff,
             gpt_parse_coco=gen_gpt_parse_coco, gpt_parse=gen_gpt_parse, tokenizer=gen_tokenizer,
@@ -637,6 +663,6 @@ if __name__ == "__main__":
     for name, fn in GENS.items():
         if a.only and name != a.only:
             continue
-        if a.skip_large and name == "gradcam_large":
+        if a.skip_large and name in ("gradcam_large", "gradcam_large_768"):
             continue
         fn()

@@ -198,3 +198,51 @@ def test_build_model_from_checkpoint_matches_reference_load_checkpoint(tmp_path,
     assert np.abs(blocks[7][9].numpy() - g["map_7_9"]).max() < 1e-4
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=5e-3)
     model.engine.close()
+
+
+def test_compute_gradcam_ensemble_full_return_value_all_layers_and_heads(golden_dir):
+    """f-4 (layer / head sweep): with stash_layer = 0 every [layer][head] entry of compute_gradcam_ensemble's return value
+    (blip_image_text_matching.py:411-435, 12 x 12 maps) comes out of ONE forward -- against the reference's own 144 maps;
+    hook accessors follow the layer; layers below stash_layer fail loudly."""
+    from pnp_ovss import config as C, synth
+    from pnp_ovss.model import build_model
+    from lavis.models.blip_models.blip_image_text_matching import compute_gradcam_ensemble
+    g = np.load(os.path.join(golden_dir, "gradcam_small.npz"))
+    cfg = C.ModelCfg(**json.loads(str(g["cfg"])))
+    model = build_model(cfg=cfg, max_batch=2, max_text_len=32, stash_layer=0, mode="f32", seed=int(g["weight_seed"]))
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=int(g["image_seed"]))
+    caps = [str(c) for c in g["captions"]]
+    tok500 = model.module.tokenizer(caps, padding="max_length", max_length=500, return_tensors="pt")
+    blocks, _, _ = compute_gradcam_ensemble(argparse.Namespace(img_size=cfg.img_size), model.module, torch.from_numpy(imgs), caps, tok500)
+    worst = 0.0
+    for layer in (11, 0, 7, 3, 8, 1, 2, 4, 5, 6, 9, 10):            # any order: each layer re-runs the (text-only) backward
+        for head in range(12):
+            worst = max(worst, float(np.abs(blocks[layer][head].numpy() - g["maps"][layer, head]).max()))
+    assert worst < 1e-4, worst
+    hook0 = model.module.text_encoder.base_model.base_model.encoder.layer[0].crossattention.self
+    np.testing.assert_allclose(hook0.get_attn_gradients().cpu().numpy(), g["dP0"], atol=3e-4)
+    model.engine.close()
+    model = build_model(cfg=cfg, max_batch=2, max_text_len=32, stash_layer=7, mode="f32", seed=int(g["weight_seed"]))
+    blocks, _, _ = compute_gradcam_ensemble(argparse.Namespace(img_size=cfg.img_size), model.module, torch.from_numpy(imgs), caps, tok500)
+    assert np.abs(blocks[9][3].numpy() - g["maps"][9, 3]).max() < 1e-4      # layers above stash_layer are there too
+    with pytest.raises(RuntimeError):
+        blocks[3][0]
+    model.engine.close()
+
+
+def test_cli_layer_head_sweep_and_crf_only(tmp_path):
+    """`--ensemble_blocks saveall --layer 12` (sweep restricted to the last text layer: 12 heads) with `--postprocess crf`
+    (PnP.py:1013-1026, CRF on the un-blurred maps): one histogram file per (layer, head) and batch, pixel totals exact."""
+    save = tmp_path / "sweep"
+    cmd = [sys.executable, os.path.join(ROOT, "pnp-ovss_amd", "PnP_OVSS_0514_updated_segmentation.py"),
+           "--save_path", str(save), "--world_size", "1", "--img_size", "336", "--del_patch_num", "sort_thresh005",
+           "--batch_size", "2", "--max_att_block_num", "8", "--drop_iter", "2", "--prune_att_head", "9", "--threshold", "0.15",
+           "--postprocess", "crf", "--data_type", "synthetic", "--synthetic_images", "2", "--ensemble_blocks", "saveall",
+           "--layer", "12", "--dtype", "bf16x3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    files = sorted(glob.glob(str(save / "all_drop_hist_with_filtered_caption" / "*.npy")))
+    assert len(files) == 12 and all("_max_blocknum_12_atthead_" in f for f in files)
+    for f in files:
+        h = np.load(f)
+        assert h.shape == (21, 21) and h.sum() == 2 * 336 * 336

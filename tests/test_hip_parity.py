@@ -530,6 +530,29 @@ def test_postprocess_stages_bit_exact_vs_oracle(data_type, scale01):
         assert idb[b + 1] - idb[b] == stats[1]                                  # same number of lattice points
 
 
+def test_postprocess_crf_only_mode_vs_oracle():
+    """`--postprocess crf` (PnP.py:1013-1026: DenseCRF on the thresholded / upsampled maps, no blur) against the oracle:
+    labels bit-exact, for both branches' scaling rules."""
+    cfg, maps, pieces, classes, sizes, rgb, best, gts = _post_case(seed=5)
+    e = _engine(cfg, 4, False)
+    if not getattr(e, "_reserved", False):
+        e.post_reserve(4, 4 * 128 * 128, 128 * 128, 8, 0)
+        e._reserved = True
+    has_bg = [True, True, True]
+    K = [len(b) + 1 for b in best]
+    d_rgb = _dev(np.concatenate([r.reshape(-1) for r in rgb]))
+    e.post_prepare(sizes, _plans(pieces, [len(b) for b in best]), [_lut(b, True, k) for b, k in zip(best, K)], has_bg,
+                   rgb=d_rgb, gt=None, want_crf=True)
+    for scale01 in (True, False):
+        labels = e.split_labels(e.postprocess(_dev(maps), 0.15, scale01, "crf"))
+        torch.cuda.synchronize()
+        for b in range(3):
+            merged = OP.merge_tokens(maps[b], pieces[b], len(best[b]))
+            pre = OP.threshold_upsample(merged, sizes[b][0], sizes[b][1], 0.15, scale01, True)
+            lab = OP.postprocess("crf", pre, rgb[b], sizes[b])
+            np.testing.assert_array_equal(labels[b].cpu().numpy().astype(np.float32), OP.remap_labels(lab, best[b], True))
+
+
 def test_postprocess_nan_channel_semantics():
     """An all-zero class map blurs to 0/0 = NaN (PnP.py:1151-1152); the reference's argmax then
     returns that channel everywhere.  The device path must reproduce it (oracle is pinned on it)."""
@@ -745,6 +768,95 @@ def test_bf16_vs_f32_divergence_is_bounded():
     assert min(overlap) >= 8, overlap                                        # iteration 0: at most 2 of 10 picks move
     same = sum(set(pf[b, :10]) == set(pb[b, :10]) for b in range(3))
     assert same >= 1
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_gradcam_large_768_vs_reference_golden(mode):
+    """BASELINE config 5 at full model size: BLIP-ITM-large, img_size 768 (ViT re-tiled to 48 x 48 patches = 2305 image
+    tokens), 40-class prompt (L = 45), B = 1, against the reference's own compute_gradcam_ensemble run
+    (tests/golden/make_golden.py:gen_gradcam_large_768): the selected map [7][9] and the logits."""
+    g = _golden("gradcam_large_768.npz")
+    cfg = _cfg(g)
+    assert cfg.img_size == 768 and cfg.n_img_tokens == 2305
+    _, imgs = synth.synth_images(1, 768, seed=int(g["image_seed"]))
+    ids, mask = synth.synth_tokens(cfg, [int(g["n_classes"])], seed=int(g["token_seed"]))
+    L = int(mask.sum(1).max())
+    e = _engine(cfg, int(g["weight_seed"]), mode, max_batch=1, max_text_len=48)
+    out, logits = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 9)
+    torch.cuda.synchronize()
+    got, ref = out.cpu().numpy(), g["map_7_9"]
+    assert got.shape == ref.shape == (1, L - 1, 48, 48)
+    assert np.abs(got - ref).max() < 1e-4
+    assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < (1e-2 if mode == "f32" else 3e-2)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-2)
+    out2, _ = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 3, layer=11)
+    torch.cuda.synchronize()
+    assert np.abs(out2.cpu().numpy() - g["map_11_3"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_gradcam_large_59_class_caption_vs_oracle(mode):
+    """BASELINE config 3 workload shape: a Pascal-Context caption with all 59 class names (L = 64 tokens with one piece per
+    class) through BLIP-ITM-large at 336^2 -- the long-caption paths of the text kernels at full width -- against the
+    oracle (itself pinned to the reference at L = 25 on the same weights)."""
+    cfg = C.blip_itm_large(336)
+    W = synth.synth_state_dict(cfg, 0)
+    _, imgs = synth.synth_images(1, 336, seed=77)
+    ids, mask = synth.synth_tokens(cfg, [59], seed=77)
+    L = int(mask.sum(1).max())
+    assert L == 64
+    e = _engine(cfg, 0, mode, max_batch=1, max_text_len=64)
+    out, logits = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 9)
+    torch.cuda.synchronize()
+    maps, ref_logits, _ = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7])
+    ref = maps[7][:, 9]
+    assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
+    assert np.abs(_norm01(out.cpu().numpy()[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < (5e-3 if mode == "f32" else 2e-2)
+    np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, rtol=0, atol=2e-2)
+
+
+def test_ade20k_768_150_channel_postprocess_properties():
+    """BASELINE config 5 post-processing at its real size: two images (768 x 768 and 512 x 683), 150 classes -> 150
+    channels (no background channel: >= 3 classes, PnP.py:378-379), blur (sigma 38.4, radius 154) + DenseCRF.  The oracle
+    does not finish at this size in test time, so size-independent properties: marginals are distributions, every
+    pixel counted once in the histogram, labels within the class range, run-to-run determinism, and the workspace the
+    engine reserved for it stays within a stated bound (sizing rule: 288 GB of HBM, upper-bound lattices)."""
+    cfg = C.blip_itm_small(768)                                 # post-processing only depends on the 48 x 48 patch grid
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    e = Engine(cfg, max_batch=2, max_text_len=160, stash_layer=7, mode="f32")
+    base = e.allocated_bytes()
+    sizes = [(768, 768), (512, 683)]
+    C_ = 150
+    total = sum(h * w for h, w in sizes)
+    e.post_reserve(2, 2 * 768 * 768, 768 * 768, 152, 0)
+    reserved = e.allocated_bytes() - base
+    # maps 3 x TP x K x 4 + CRF rows (unary, Q; two groups if they fit) + bilateral lattice (6 entries / pixel) + values
+    assert reserved < 48 * 2 ** 30, reserved / 2 ** 30
+    rng = np.random.default_rng(11)
+    T = 3 + C_ + 1
+    maps = (rng.random((2, T, 48, 48), dtype=np.float32) ** 4)
+    rgb = [np.clip(np.repeat(np.repeat(rng.integers(0, 256, size=((h + 7) // 8, (w + 7) // 8, 3)), 8, 0), 8, 1)[:h, :w]
+                   + rng.integers(-6, 7, size=(h, w, 3)), 0, 255).astype(np.uint8) for h, w in sizes]
+    gt = [rng.integers(0, 151, size=s).astype(np.float32) for s in sizes]
+    plans = [[([i], 1) for i in range(C_)]] * 2
+    luts = [[i + 1 for i in range(C_)]] * 2                      # no background: argmax index i -> class i + 1
+    e.post_prepare(sizes, plans, luts, [False, False], rgb=_dev(np.concatenate([r.reshape(-1) for r in rgb])),
+                   gt=_dev(np.concatenate([x.reshape(-1) for x in gt])), want_crf=True)
+    hist = torch.zeros(151 * 151, device="cuda", dtype=torch.int64)
+    labels = e.postprocess(_dev(maps), 0.15, False, "blur+crf", 151, hist)
+    torch.cuda.synchronize()
+    lab = labels.cpu().numpy()
+    assert lab.shape == (total,) and lab.min() >= 1 and lab.max() <= 150
+    h = hist.cpu().numpy().reshape(151, 151)
+    assert h.sum() == total
+    np.testing.assert_array_equal(h.sum(0), np.bincount(lab, minlength=151))
+    q = torch.cat([x.reshape(-1, C_) for x in e.post_q()])
+    assert float((q.sum(1) - 1).abs().max()) < 1e-4 and bool(torch.isfinite(q).all())
+    labels2 = e.postprocess(_dev(maps), 0.15, False, "blur+crf")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(labels2.cpu().numpy(), lab)
+    e.close()
 
 
 def test_gradcam_768_geometry_vs_oracle():
