@@ -335,6 +335,13 @@ class Engine:
                                                      layer, head, _ptr(out), _ptr(logits), _stream()), "pnp_compute_gradcam_layer")
         return out, logits
 
+    def drop_step(self, gradcam, g0, agg, dropped, picks, it, npick=10):
+        """One bookkeeping step of the drop loop (PnP.py:619-647, 716-721) on a gathered map: updates g0 (it == 0), the
+        running sum agg, the dropped-patch mask and the pick list, all on device."""
+        B, T = gradcam.shape[0], gradcam.shape[1]
+        self._chk(self.lib.pnp_drop_step(self.h, _ptr(gradcam), _ptr(g0), _ptr(agg), _ptr(dropped), _ptr(picks), it, B, T, npick,
+                                         picks.shape[1], _stream()), "pnp_drop_step")
+
     def drop_loop(self, images, ids, mask, L, head, drop_iter, npick=10, layer=None):
         B, ld = ids.shape
         layer = self.stash_layer if layer is None else int(layer)

@@ -1,9 +1,11 @@
-"""Scratch probe: per-workgroup phase timing of the wide-tile GEMM (PNP_GEMM_VARIANT=4 PNP_GEMM_STAMPS=1)."""
+"""Scratch probe: per-workgroup phase timing of the wide-tile GEMM.  Needs the DEV build of the library
+(make -C pnp-ovss_amd/csrc DEV=1 OBJDIR=build_dev OUT=../pnp_ovss/libpnp_hip_dev.so) and PNP_GEMM_STAMPS=1."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "pnp-ovss_amd"))
 import numpy as np, torch
 from pnp_ovss import hip
+hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), "libpnp_hip_dev.so")
 lib = hip.load_library()
 def run(M, N, K, bias, resid, f32out, tout, mode, tag):
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); B = (0.02 * torch.randn(N, K, device="cuda")).to(torch.bfloat16)
