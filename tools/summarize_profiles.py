@@ -1,0 +1,92 @@
+"""Turn the raw rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/<tag>_*) into the small committed summaries
+under profiles/: kernel-stats table, MFMA-busy table, HBM traffic per launch (FETCH_SIZE doubled for 16-byte-per-lane
+reads on gfx950, as MI355X_MICROARCH.md prescribes) for the GEMM and the CRF kernels.
+usage: python tools/summarize_profiles.py r02"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    return name.replace("pnp::", "").split("(")[0][:80]
+
+
+def kernel_stats(sub, out):
+    rows = list(csv.DictReader(open(os.path.join(G, f"{TAG}_{sub}", "prof_kernel_stats.csv"))))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    lines = [f"# rocprofv3 --kernel-trace --stats of `python3 bench.py {'--dtype bf16x3 ' if 'x3' in sub else ''}--steps 2 --warmup 1 "
+             f"--no-cpu-baseline --no-parity-mode --no-noise12` (3 steps of 35 images in the trace)",
+             "# kernel | calls | total ms | avg us | min us | max us | % of GPU time"]
+    for r in rows:
+        t = float(r["TotalDurationNs"])
+        if t / tot < 0.0005:
+            continue
+        lines.append(f"{short(r['Name'])} | {r['Calls']} | {t / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
+                     f"{float(r['MaxNs']) / 1e3:.1f} | {100 * t / tot:.1f}")
+    lines.append(f"# total kernel time {tot / 1e6:.2f} ms = {tot / 3e6:.2f} ms per step")
+    open(os.path.join(P, out), "w").write("\n".join(lines) + "\n")
+
+
+def pmc(sub):
+    path = os.path.join(G, f"{TAG}_{sub}", "pmc_counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(collections.Counter)
+    dur = collections.defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        k = short(r["Kernel_Name"])
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        n[k][r["Counter_Name"]] += 1
+    return agg, n
+
+
+def main():
+    os.makedirs(P, exist_ok=True)
+    kernel_stats("trace", f"{TAG}_bench_kernel_stats_summary.txt")
+    if os.path.exists(os.path.join(G, f"{TAG}_trace_x3")):
+        kernel_stats("trace_x3", f"{TAG}_bench_bf16x3_kernel_stats_summary.txt")
+    agg, n = pmc("pmc_mfma")
+    out = {"note": "per launch; GRBM_GUI_ACTIVE is summed over the 8 XCDs (cycles = /8); SQ_VALU_MFMA_BUSY_CYCLES is summed over the "
+                   "1024 SIMDs; mfma_busy_frac = busy / (cycles * 1024): share of SIMD-cycles with the matrix pipe busy at the clock "
+                   "the chip actually held", "kernels": {}}
+    for k, v in agg.items():
+        c = n[k]["GRBM_GUI_ACTIVE"]
+        if not c or "SQ_VALU_MFMA_BUSY_CYCLES" not in v:
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"] / c / 8
+        out["kernels"][k] = {"launches": c, "cycles_per_launch": cyc, "mfma_busy_cycles_per_launch": v["SQ_VALU_MFMA_BUSY_CYCLES"] / c,
+                             "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / c / (cyc * 1024)}
+    json.dump(out, open(os.path.join(P, f"{TAG}_mfma_busy.json"), "w"), indent=1)
+    fa, fn = pmc("pmc_FETCH_SIZE")
+    wa, wn = pmc("pmc_WRITE_SIZE")
+    tr = {"note": "HBM-side bytes per launch: FETCH_SIZE (KB, doubled: gfx950 reports half of wide coalesced reads) + WRITE_SIZE (KB)",
+          "kernels": {}}
+    for k in fa:
+        c = fn[k]["FETCH_SIZE"]
+        w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(wn.get(k, {}).get("WRITE_SIZE", 1), 1)
+        f = fa[k]["FETCH_SIZE"] / c
+        tr["kernels"][k] = {"launches_profiled": c, "fetch_kb_raw": f, "write_kb": w,
+                            "traffic_bytes_per_launch": (2 * f + w) * 1024}
+    json.dump(tr, open(os.path.join(P, f"{TAG}_hbm_traffic.json"), "w"), indent=1)
+    g = {k: v for k, v in tr["kernels"].items() if "gemm_nt_wide" in k}
+    json.dump({"note": tr["note"], "kernels": g}, open(os.path.join(P, f"{TAG}_gemm_traffic.json"), "w"), indent=1)
+    try:
+        ta, tn = pmc("pmc_tcc")
+        json.dump({k: {"l2_hit_rate": v["TCC_HIT_sum"] / max(v["TCC_HIT_sum"] + v["TCC_MISS_sum"], 1)} for k, v in ta.items()},
+                  open(os.path.join(P, f"{TAG}_crf_l2_hit.json"), "w"), indent=1)
+    except FileNotFoundError:
+        pass
+    b = os.path.join(G, f"{TAG}_bench.json")
+    if os.path.exists(b):
+        open(os.path.join(P, f"{TAG}_bench.json"), "w").write(open(b).read())
+    print("wrote", sorted(f for f in os.listdir(P) if f.startswith(TAG)))
+
+
+if __name__ == "__main__":
+    main()
