@@ -235,6 +235,10 @@ int pnp_op_gemm_x3(const void* d_A_hi, const void* d_A_lo, int32_t lda, const vo
  * rows); it is transposed by the kernel's LDS reads and n_pad is not used. */
 int pnp_op_vit_attention(int32_t bf16, const void* d_qk, int32_t ld_qk, int32_t D, const void* d_vt, int32_t ld_vt,
                          int32_t n_pad, void* d_ctx, int32_t B, int32_t heads, int32_t N, float scale, void* stream);
+/* The same attention in split-bf16 form (compute mode 2): d_qkv_hi / d_qkv_lo [B*N, ld_qkv] hold q | k | v of every head as
+ * bf16 pairs (q of head h at column h*64, k at D + h*64, v at 2D + h*64); the context leaves as a pair [B*N, D]. */
+int pnp_op_vit_attention_x3(const void* d_qkv_hi, const void* d_qkv_lo, int32_t ld_qkv, int32_t D, void* d_ctx_hi, void* d_ctx_lo,
+                            int32_t B, int32_t heads, int32_t N, float scale, void* stream);
 int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,
                      float* d_y, void* stream);
 /* Cross-attention over the image tokens as one operator (B/med.py:229-283 forward, its autograd backward):

@@ -626,28 +626,23 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
     if (e->x3) {
         // split-bf16 ("bf16x3"): every Linear of the block is a wide-kernel launch on (hi, lo) bf16 operand pairs -- three
         // bf16 MFMA passes per product, fp32-class result; LayerNorm, the attention kernel and the GELU epilogue hand the
-        // next GEMM its operand already split.  Attention itself runs in the exact-fp32 kernel.
+        // next GEMM its operand already split; attention runs in the split form of the bf16 kernel (vit_attn32_x3_kernel).
         const size_t cap = (size_t)e->c.max_batch * N;                    // row capacity of the activation buffers
         void* const xn_lo = (char*)e->xn + cap * D * 2;
         void* const ctx_lo = (char*)e->ctx + cap * D * 2;
         void* const h1_lo = (char*)e->h1 + cap * F * 2;
+        void* const qk_lo = (char*)e->qk + cap * 3 * D * 2;
         for (int l = 0; l < e->c.vit_depth; l++) {
             const VitLayerW& w = e->vit[l];
             const char* const qkv_lo = (const char*)w.qkv_w + (size_t)3 * D * D * 2;
             KCHK(e, layernorm(1, e->x, w.n1w, w.n1b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s, xn_lo));
-            {   // q | k natural, fp32: [M, 2D]
-                GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 2 * D, D);
+            {   // q | k | v in one launch as a (hi, lo) bf16 pair: [M, 3D] each, halves of the qk buffer
+                GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 3 * D, D);
                 g.A_lo = xn_lo; g.B_lo = qkv_lo;
-                g.bias = w.qkv_b; g.out_f32 = (float*)e->qk; g.ldo = 2 * D;
+                g.bias = w.qkv_b; g.out_t = e->qk; g.out_lo = qk_lo; g.ldo_t = 3 * D;
                 KCHK(e, gemm_nt(1, g, s));
             }
-            {   // V^T fp32: [D, B*Npad] = Wv . xn^T, token columns padded per image
-                GemmArgs g = G_((const char*)w.qkv_w + (size_t)2 * D * D * 2, D, e->xn, D, D, M, D);
-                g.A_lo = qkv_lo + (size_t)2 * D * D * 2; g.B_lo = xn_lo;
-                g.bias = w.qkv_b + 2 * D; g.bias_on_rows = 1; g.out_f32 = (float*)e->vt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
-                KCHK(e, gemm_nt(1, g, s));
-            }
-            KCHK(e, vit_attention(0, e->qk, 2 * D, D, e->vt, ldv, e->Npad, e->ctx, B, e->c.vit_heads, N, scale, s, ctx_lo));
+            KCHK(e, vit_attention_x3(e->qk, qk_lo, 3 * D, D, e->ctx, ctx_lo, B, e->c.vit_heads, N, scale, s));
             {
                 GemmArgs g = G_(e->ctx, D, w.proj_w, D, M, D, D);
                 g.A_lo = ctx_lo; g.B_lo = (const char*)w.proj_w + (size_t)D * D * 2;
@@ -1509,6 +1504,12 @@ extern "C" int pnp_op_vit_attention(int32_t bf, const void* d_qk, int32_t ld_qk,
                                     int32_t n_pad, void* d_ctx, int32_t B, int32_t heads, int32_t N, float scale, void* stream) {
     if (!d_qk || !d_vt || !d_ctx || B <= 0 || heads <= 0 || N <= 0) return PNP_ERR_ARG;
     return vit_attention(bf, d_qk, ld_qk, D, d_vt, ld_vt, n_pad, d_ctx, B, heads, N, scale, (hipStream_t)stream);
+}
+
+extern "C" int pnp_op_vit_attention_x3(const void* d_qkv_hi, const void* d_qkv_lo, int32_t ld_qkv, int32_t D, void* d_ctx_hi,
+                                       void* d_ctx_lo, int32_t B, int32_t heads, int32_t N, float scale, void* stream) {
+    if (B <= 0 || heads <= 0 || N <= 0 || ld_qkv < 3 * D) return PNP_ERR_ARG;
+    return vit_attention_x3(d_qkv_hi, d_qkv_lo, ld_qkv, D, d_ctx_hi, d_ctx_lo, B, heads, N, scale, (hipStream_t)stream);
 }
 
 extern "C" int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float eps, int32_t rows, int32_t D,

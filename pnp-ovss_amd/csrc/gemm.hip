@@ -390,8 +390,9 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 // (terms dropped: a_lo.b_lo, 2^-18 relative, and what two bf16 cannot hold of an fp32 operand, 2^-17) at a third of
 // the bf16 MFMA rate, i.e. ~5x the fp32 MFMA rate (v_mfma_f32_16x16x4_f32 runs at 1/16 of bf16).  Only the slab ->
 // source-array map of the DMA changes; the MFMA stream is the bf16 kernel's.
+//      7 = +bias -> split bf16 pair
 enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3, WIDE_BIAS_F32 = 4, WIDE_TOKCOLS_F32 = 5,
-       WIDE_GELU_SPLIT = 6 };
+       WIDE_GELU_SPLIT = 6, WIDE_SPLIT = 7 };
 constexpr int kWideStageRow = 68;                                  // floats per staged row (64 + 4 pad)
 constexpr int kWideStageBytes = 8 * 32 * kWideStageRow * 4;        // 8 waves x 32 rows
 constexpr int kWideSmem = 65536 + kWideStageBytes;                 // slot 0 | slot 1 overlaid by the staging area
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         f32x4 rv[8];
         f32x4 bacc[TN][4];                          // bf16 epilogues: bias in the accumulator layout
-        if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16 || EPI == WIDE_GELU_SPLIT) {
+        if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16 || EPI == WIDE_GELU_SPLIT || EPI == WIDE_SPLIT) {
 #pragma unroll
             for (int i = 0; i < TN; i++)
 #pragma unroll
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                     }
                 }
             }
-        } else if constexpr (EPI == WIDE_GELU_SPLIT) {
+        } else if constexpr (EPI == WIDE_GELU_SPLIT || EPI == WIDE_SPLIT) {
             // bias + erf-form GELU (|erf error| <= 1.5e-7) in the accumulator layout, written back into the accumulators;
             // then two passes over the bf16 staging of the plain bf16 epilogue: hi = bf16(v) -> out_t, lo = bf16(v - hi)
             // -> out_lo (the pair carries 16 significant bits of v)
@@ -726,7 +727,10 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[i][j][gq * 4 + e] = gelu_erf_fast(acc[i][j][gq * 4 + e] + bacc[i][gq][e]);
+                        for (int e = 0; e < 4; e++) {
+                            const float v = acc[i][j][gq * 4 + e] + bacc[i][gq][e];
+                            acc[i][j][gq * 4 + e] = EPI == WIDE_GELU_SPLIT ? gelu_erf_fast(v) : v;
+                        }
 #pragma unroll
             for (int part = 0; part < 2; part++) {
                 bf16* const obase = reinterpret_cast<bf16*>(part ? g.out_lo : g.out_t) + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo_t + n;
@@ -864,6 +868,7 @@ static int wide_epilogue_kind(const GemmArgs& g) {
         if (g.mode == GEMM_EPI_LINEAR && g.resid && g.out_f32 && !g.out_t) return WIDE_RESID_F32;
         if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_f32 && !g.out_t) return WIDE_BIAS_F32;
         if (g.mode == GEMM_EPI_GELU && !g.resid && g.out_t && g.out_lo && !g.out_f32) return WIDE_GELU_SPLIT;
+        if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_t && g.out_lo && !g.out_f32) return WIDE_SPLIT;
         return -1;
     }
     if (g.mode == GEMM_EPI_LINEAR && !g.resid && g.out_t && !g.out_f32 && (g.bias_on_rows || !g.bias) && (g.col_div > 0 || g.bias_on_rows))
@@ -1110,7 +1115,8 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
         g.N = (g.Nvalid + 255) / 256 * 256;
         r = wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32, true>(g, s)
             : wide == WIDE_BIAS_F32 ? launch_wide<WIDE_BIAS_F32, true>(g, s)
-            : wide == WIDE_GELU_SPLIT ? launch_wide<WIDE_GELU_SPLIT, true>(g, s) : launch_wide<WIDE_TOKCOLS_F32, true>(g, s);
+            : wide == WIDE_GELU_SPLIT ? launch_wide<WIDE_GELU_SPLIT, true>(g, s)
+            : wide == WIDE_SPLIT ? launch_wide<WIDE_SPLIT, true>(g, s) : launch_wide<WIDE_TOKCOLS_F32, true>(g, s);
     } else if (wide >= 0 && (variant == 4 || (variant == 0 && tiles256 >= 128))) {
         g.N = (g.Nvalid + 255) / 256 * 256;
         r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16, false>(g, s)

@@ -47,6 +47,9 @@ int layernorm(int bf, const float* x, const float* w, const float* b, float eps,
 int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
                   int H, int N, float scale, hipStream_t s, void* ctx_lo = nullptr);
 
+int vit_attention_x3(const void* qkv_hi, const void* qkv_lo, int ld_qk, int D, void* ctx_hi, void* ctx_lo, int B, int H, int N,
+                     float scale, hipStream_t s);
+
 // text_kernels.hip
 int text_embed(const int64_t* ids, int ld_ids, const float* word, const float* pos, float* out, int B, int L, int H,
                int enc_id, int vocab, hipStream_t s);

@@ -414,6 +414,169 @@ __global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict_
     }
 }
 
+// Split-bf16 ("bf16x3") form of the kernel above for compute mode 2: q, k, v arrive as (hi, lo) bf16 pairs (the fused
+// q|k|v rows of the split-output GEMM), both products run as three bf16 MFMA passes -- S = K_hi.Q_hi + K_hi.Q_lo + K_lo.Q_hi,
+// O += V_hi.P_hi + V_hi.P_lo + V_lo.P_hi with P split after the exp2 -- and the context leaves as a (hi, lo) pair for the
+// proj GEMM.  Same tiling, ring and softmax; the ring slot holds four tiles (K_hi, V_hi, K_lo, V_lo).
+__global__ __launch_bounds__(512) void vit_attn32_x3_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ qk_lo, int ld_qk, int D,
+                                                            const bf16* __restrict__ vt, const bf16* __restrict__ vt_lo, int ld_vt,
+                                                            bf16* __restrict__ ctx, bf16* __restrict__ ctx_lo, int N, float scale, int nqw) {
+    constexpr int ROWB = 128, TILE = 64 * ROWB;         // K tile [64 keys][64 d], V tile [64 keys][64 d] (transposed on the read)
+    __shared__ __attribute__((aligned(16))) char ring[2][4 * TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const size_t row0 = (size_t)b * N;
+    const int qw = blockIdx.x * nwaves + wave;
+    int qrow = qw * 32 + l32;
+    const bool q_valid = qw < nqw && qrow < N;
+    qrow = qrow < N ? qrow : N - 1;
+
+    bf16x8 fq[4], fql[4];
+    {
+        const size_t off = (row0 + qrow) * ld_qk + h * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            fq[ks] = *reinterpret_cast<const bf16x8*>(qk + off + ks * 16);
+            fql[ks] = *reinterpret_cast<const bf16x8*>(qk_lo + off + ks * 16);
+        }
+    }
+    const size_t koff = (row0 * ld_qk + D + h * 64) * 2, voff = (row0 * ld_vt + h * 64) * 2;
+    const char* kb[2] = {reinterpret_cast<const char*>(qk) + koff, reinterpret_cast<const char*>(qk_lo) + koff};
+    const char* vb[2] = {reinterpret_cast<const char*>(vt) + voff, reinterpret_cast<const char*>(vt_lo) + voff};
+    const int prow = lane >> 3, pc = lane & 7;
+    auto issue_tile = [&](int t) {
+        char* dst = ring[t & 1];
+        for (int p = wave; p < 32; p += nwaves) {       // pieces 0-7 K_hi, 8-15 V_hi, 16-23 K_lo, 24-31 V_lo
+            const int row = (p & 7) * 8 + prow;
+            const int sc = pc ^ ((row >> 1) & 7);
+            int key = t * 64 + row;
+            key = key < N ? key : N - 1;
+            const int part = p >> 4;
+            const char* src = (p & 8) ? vb[part] + (size_t)key * ld_vt * 2 + sc * 16 : kb[part] + (size_t)key * ld_qk * 2 + sc * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = scale * 1.4426950408889634f;
+    const int sw = (l32 >> 1) & 7;
+    const int ntiles = (N + 63) / 64;
+
+    issue_tile(0);
+    for (int t = 0; t < ntiles; t++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < ntiles) issue_tile(t + 1);
+        const char* Ks = ring[t & 1];
+        const char* Vs = Ks + TILE;
+        const char* Kl = Ks + 2 * TILE;
+        const char* Vl = Ks + 3 * TILE;
+
+        f32x16 s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+            s[kt] = zero16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {            // small terms first, the hi.hi term last
+                const int a = (kt * 32 + l32) * ROWB + (((ks * 2 + hi) ^ sw) << 4);
+                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(Kl + a);
+                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(Ks + a);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, fq[ks], s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, fql[ks], s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, fq[ks], s[kt], 0, 0, 0);
+            }
+        }
+        if (t == ntiles - 1 && (N & 63)) {
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int key = t * 64 + kt * 32 + (e >> 2) * 8 + hi * 4 + (e & 3);
+                    if (key >= N) s[kt][e] = -INFINITY;
+                }
+        }
+        float mx = m_run;
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) mx = fmaxf(mx, s[kt][e]);
+        const float m_new = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+#pragma unroll
+            for (int i = 0; i < 2; i++) o[i] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+        }
+        const float mc = -m_run * c;
+        bf16x8 fp[4], fpl[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][e], c, mc));
+                l_run += p;
+                const bf16 ph = (bf16)p;
+                fp[kt * 2 + (e >> 3)][e & 7] = ph;
+                fpl[kt * 2 + (e >> 3)][e & 7] = (bf16)(p - (float)ph);
+            }
+        const int grp_d = ((lane >> 4) & 1) * 16, tq = (lane >> 2) & 3, tp = lane & 3;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int dt = 0; dt < 2; dt++) {
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                bf16x8 fv[2];
+#pragma unroll
+                for (int part = 0; part < 2; part++) {
+                    const char* V = part ? Vl : Vs;
+                    s16x4 pr[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int key = 16 * j + 8 * u + 4 * hi + tq;
+                        const int col = dt * 32 + grp_d + 4 * tp;
+                        const char* a = V + key * ROWB + ((((col >> 3)) ^ ((key >> 1) & 7)) << 4) + (col & 7) * 2;
+                        pr[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+                    }
+                    const bf16x4 lo = __builtin_bit_cast(bf16x4, pr[0]), hh = __builtin_bit_cast(bf16x4, pr[1]);
+                    fv[part] = bf16x8{lo[0], lo[1], lo[2], lo[3], hh[0], hh[1], hh[2], hh[3]};
+                }
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[1], fp[j], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[0], fpl[j], o[dt], 0, 0, 0);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[0], fp[j], o[dt], 0, 0, 0);
+            }
+    }
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (q_valid) {
+        const float inv = 1.0f / l_run;
+        const size_t off = (row0 + qrow) * D + h * 64 + hi * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; dt++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                bf16x4 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = o[dt][g4 * 4 + e] * inv;
+                    ph[e] = (bf16)v;
+                    pl[e] = (bf16)(v - (float)ph[e]);
+                }
+                *reinterpret_cast<bf16x4*>(ctx + off + dt * 32 + g4 * 8) = ph;
+                *reinterpret_cast<bf16x4*>(ctx_lo + off + dt * 32 + g4 * 8) = pl;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ host
 // ctx_lo != nullptr (fp32 kernel only): the output is written as a split-bf16 pair (ctx = hi, ctx_lo = lo)
 int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int ld_vt, int Npad, void* ctx, int B,
@@ -431,6 +594,19 @@ int vit_attention(int bf, const void* qk, int ld_qk, int D, const void* vt, int 
     dim3 grid((N + 63) / 64, H, B);
     hipLaunchKernelGGL((vit_attn_kernel<float>), grid, dim3(256), 0, s, (const float*)qk, ld_qk, D, (const float*)vt, ld_vt,
                        Npad, ctx_lo ? nullptr : (float*)ctx, N, scale, ctx_lo ? (bf16*)ctx : nullptr, (bf16*)ctx_lo);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+// split-bf16 attention (compute mode 2): q|k|v rows as (hi, lo) bf16 pairs [B*N, ld_qk] each, context as a pair
+int vit_attention_x3(const void* qkv_hi, const void* qkv_lo, int ld_qk, int D, void* ctx_hi, void* ctx_lo, int B, int H, int N,
+                     float scale, hipStream_t s) {
+    if (D != H * 64 || !qkv_hi || !qkv_lo || !ctx_hi || !ctx_lo) return PNP_ERR_ARG;
+    const int nqw = (N + 31) / 32;
+    const int max_wpb = 8;
+    const int nblk = (nqw + max_wpb - 1) / max_wpb, wpb = (nqw + nblk - 1) / nblk;
+    const bf16 *qh = (const bf16*)qkv_hi, *ql = (const bf16*)qkv_lo;
+    hipLaunchKernelGGL(vit_attn32_x3_kernel, dim3(nblk, H, B), dim3(wpb * 64), 0, s, qh, ql, ld_qk, D, qh + 2 * D, ql + 2 * D, ld_qk,
+                       (bf16*)ctx_hi, (bf16*)ctx_lo, N, scale, nqw);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpnp_hip.so")
+LIB_PATH = os.environ.get("PNP_HIP_LIB") or os.path.join(_HERE, "libpnp_hip.so")     # override: development builds of the library
 
 
 class PnpConfig(C.Structure):
@@ -83,6 +83,7 @@ def load_library():
         "pnp_op_gemm_ex": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, vp]),
         "pnp_op_gemm_tokcols": (i32, [i32, vp, i32, vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
         "pnp_op_vit_attention": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, f32, vp]),
+        "pnp_op_vit_attention_x3": (i32, [vp, vp, i32, i32, vp, vp, i32, i32, i32, f32, vp]),
         "pnp_preprocess_images": (i32, [vp, vp, i32, i32, i32, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
         "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
         "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
@@ -105,7 +106,8 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
             "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images",
             "pnp_cross_kv", "pnp_profile_read_stage", "pnp_op_split", "pnp_op_gemm_x3",
-            "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer", "pnp_allocated_bytes"]
+            "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer", "pnp_allocated_bytes",
+            "pnp_op_vit_attention_x3"]
 
 
 class _DevView:

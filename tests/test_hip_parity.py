@@ -99,7 +99,7 @@ def _split(t):
     return hi, lo
 
 
-@pytest.mark.parametrize("kind", ["bias_f32", "resid_f32", "gelu_split", "tokcols_f32"])
+@pytest.mark.parametrize("kind", ["bias_f32", "resid_f32", "gelu_split", "plain_split", "tokcols_f32"])
 @pytest.mark.parametrize("shape", [(4100, 2048, 256), (2200, 3840, 64), (70, 300, 128)])
 def test_gemm_split_bf16_x3(kind, shape):
     """The wide kernel's split-bf16 form (compute mode 2): fp32 operands as (hi, lo) bf16 pairs, three bf16 MFMA passes,
@@ -142,13 +142,15 @@ def test_gemm_split_bf16_x3(kind, shape):
         assert float((got[:, :, :div].abs() * (~live.view(nimg, div))).max()) == 0.0
         return
     bias = torch.randn(N, generator=g).cuda()
-    if kind == "gelu_split":
+    if kind in ("gelu_split", "plain_split"):
         hi = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         lo = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
         assert lib.pnp_op_gemm_x3(p(Ah), p(Al), K, p(Bh), p(Bl), K, M, N, K, p(bias), 0, None, 0, None, 0, p(hi), p(lo), N,
-                                  1, 0, 0, None) == 0
+                                  1 if kind == "gelu_split" else 0, 0, 0, None) == 0
         torch.cuda.synchronize()
-        want = torch.nn.functional.gelu(ref + bias.double())
+        want = ref + bias.double()
+        if kind == "gelu_split":
+            want = torch.nn.functional.gelu(want)
         got = hi.double() + lo.double()
         err = float((got - want).abs().max())
         assert err < tol + 2 ** -16 * float(want.abs().max()), (err, tol)
@@ -165,6 +167,29 @@ def test_gemm_split_bf16_x3(kind, shape):
     # and it really is ~2 orders of magnitude closer to the fp32 product than one bf16 pass
     one = Ah.double() @ Bh.double().t() + bias.double() + (resid.double() if resid is not None else 0)
     assert err < 0.05 * float((one - want).abs().max())
+
+
+@pytest.mark.parametrize("N", [17, 442, 577, 2305])
+def test_vit_attention_split_bf16_x3(N):
+    """ViT self-attention in split-bf16 form (vit_attn32_x3_kernel): q, k, v as (hi, lo) bf16 pairs, both products as three
+    bf16 MFMA passes, P split after the exp2.  Against float64 attention of the ORIGINAL fp32 q, k, v: fp32-class error
+    (plain bf16 attention is ~3e-3 here), ragged token counts incl. the 336^2 (442) and 768^2 (2305) geometries."""
+    from pnp_ovss import hip
+    lib = hip.load_library()
+    B, H, D = 2, 4, 256
+    g = torch.Generator().manual_seed(N)
+    qkv = (torch.randn(B * N, 3 * D, generator=g) * 1.5).cuda()
+    hi, lo = _split(qkv)
+    ch = torch.zeros(B * N, D, device="cuda", dtype=torch.bfloat16)
+    cl = torch.zeros(B * N, D, device="cuda", dtype=torch.bfloat16)
+    assert lib.pnp_op_vit_attention_x3(hi.data_ptr(), lo.data_ptr(), 3 * D, D, ch.data_ptr(), cl.data_ptr(), B, H, N, 0.125, None) == 0
+    torch.cuda.synchronize()
+    x = qkv.double().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
+    ref = (att @ x[2]).permute(0, 2, 1, 3).reshape(B * N, D)
+    got = ch.double() + cl.double()
+    err = float((got - ref).abs().max())
+    assert err < 5e-5 * max(1.0, float(ref.abs().max())), err
 
 
 @pytest.mark.parametrize("kind", ["bias_bf16", "gelu_bf16", "resid_f32", "tokcols"])
