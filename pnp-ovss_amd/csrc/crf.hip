@@ -305,18 +305,7 @@ __global__ void crf_norm_kernel(const CrfLattice L, const PostDesc* __restrict__
 // are cut into 8 equal slices, one per XCD (with 35 images three XCDs would otherwise sweep a fifth image while five
 // idle: 12.5 % of every iteration kernel).
 __device__ __forceinline__ bool xcd_work(int i, int xcd, int img0, int nimg, int& b, int& part, int& parts) {
-#ifdef PNP_CRF_ALLSLICED
-    const int full = 0;            // experiment: every image swept by all 8 XCDs (one image in flight chip-wide)
-    if (i < nimg) {
-        b = img0 + i;
-        part = xcd;
-        parts = 8;
-        return true;
-    }
-    return false;
-#else
     const int full = nimg >> 3;
-#endif
     if (i < full) {
         b = img0 + i * 8 + xcd;
         part = 0;

@@ -473,6 +473,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     int tile = blockIdx.x;
     if (tile >= ntiles) return;
     int m0, n0;
+    bool drain32 = false;                           // the previous tile's epilogue left >= 32 stores behind this tile's slab 0
     stamp(0);
     set_tile(tile, m0, n0);
 #pragma unroll
@@ -513,8 +514,12 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - (TM + TN), 0);
         };
 
-        // slab 0 of this tile is in flight (issued before the previous tile's epilogue, or above)
-        PNP_WAIT_VM(0);
+        // slab 0 of this tile is in flight (issued before the previous tile's epilogue, or above).  vmcnt counts in
+        // issue order, so after a full-tile epilogue that issued >= 32 stores behind the DMA pieces, "at most 32
+        // outstanding" already means the slab has landed: the stores of the previous tile keep draining under the first
+        // sub-steps of this one instead of stalling every wave here
+        if (drain32) PNP_WAIT_VM(32);
+        else PNP_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();               // slab 0 complete; staging area (slot 1) no longer read
         if (nk > 1) {
 #pragma unroll
@@ -849,6 +854,8 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         if (tile == (int)blockIdx.x) stamp(1);     // diagnostics: first tile's epilogue done (stores issued)
         if (next >= ntiles) break;
         tile = next;
+        // every lane of a full tile executes all of the epilogue's stores (32 per wave, 64 for the split pair)
+        drain32 = (EPI != WIDE_TOKCOLS_BF16 && EPI != WIDE_TOKCOLS_F32) && (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
     }
     if (g.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -63,8 +63,17 @@ class _Base:
         if torch.cuda.is_available():
             torch.cuda.set_device(self.rank)                     # this generator may run in a prefetch thread (rank = device)
         idx = self._indices(len(self))
+        # JPEG / PNG decode of a batch on a small thread pool (Pillow releases the GIL while decoding): at ~300 images/s
+        # per GPU one decoding thread (2-4 ms per VOC-sized image) would be the bottleneck (the reference decodes on the
+        # main thread, num_workers = 0, PnP.py:61)
+        workers = int(getattr(self.args, "num_workers", 0) or 0) or min(8, os.cpu_count() or 1)
+        pool = None
+        if workers > 1 and not isinstance(self, SyntheticDataset):
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=workers)
         for o in range(0, len(idx), batch_size):
-            items = [self[i] for i in idx[o:o + batch_size]]
+            ids = idx[o:o + batch_size]
+            items = list(pool.map(self.__getitem__, ids)) if pool else [self[i] for i in ids]
             if items[0][0] is None:
                 from . import hip
                 filt, mean, std = self.resample

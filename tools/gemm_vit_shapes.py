@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "pnp-ovss_amd"))
 import torch
 from pnp_ovss import hip
-lib = hip.load_library()
+lib = hip.load_library()           # PNP_HIP_LIB=<dev build> + PNP_GEMM_ABLATE=3: time the 16x16x32 MFMA shape (results are garbage)
+CHECK = "exp" not in os.environ.get("PNP_HIP_LIB", "")
 def run(M, N, K, bias, resid, f32out, tout, mode, tag, check=True):
     torch.manual_seed(0)
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16); B = (0.02 * torch.randn(N, K, device="cuda")).to(torch.bfloat16)
@@ -18,14 +19,14 @@ def run(M, N, K, bias, resid, f32out, tout, mode, tag, check=True):
     for _ in range(3): assert call() == 0
     torch.cuda.synchronize()
     err = -1.0
-    if check:
+    if check and CHECK:
         ref = A.float() @ B.float().t()
         if bias: ref += bi
         if mode == 1: ref = torch.nn.functional.gelu(ref)
         if resid: ref += rs
         got = of if f32out else ot.float()
         err = float((got - ref).abs().max() / ref.abs().max())
-    n = 20; t0 = time.perf_counter()
+    n = 200; t0 = time.perf_counter()
     for _ in range(n): call()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print(f"{tag:30s} M={M} N={N} K={K}: {2*M*N*K/dt/1e12:6.0f} TF ({dt*1e6:.0f} us) relerr {err:.1e}", flush=True)
