@@ -220,3 +220,33 @@ def test_merge_checkpoint_matches_reference_load_checkpoint():
     np.testing.assert_allclose(np.asarray(state["visual_encoder.pos_embed"]), g["pos_embed"], rtol=0, atol=1e-6)
     np.testing.assert_array_equal(np.asarray(state["itm_head.bias"]), g["itm_head_bias"])       # init value kept
     np.testing.assert_array_equal(np.asarray(state["itm_head.weight"]), ck["itm_head.weight"])  # checkpoint value taken
+
+
+def test_host_tables_equal_sequential_reference_semantics_randomised():
+    """Property tests of the two host-side tables the device kernels are fed with, against direct restatements of the
+    reference's sequential code on random inputs: remap_lut == the in-place descending remap applied to every pixel value
+    (PnP.py:390-399 / PnPc.py:458-463, collisions included), merge_plan == the oracle's token walk (PnP.py:820-853)."""
+    from oracle import pipeline_np as OP
+    rng = np.random.default_rng(2024)
+    for _ in range(300):
+        n = int(rng.integers(1, 12))
+        best = [int(v) for v in rng.integers(0, 20, size=n)]
+        bg = bool(rng.integers(0, 2))
+        ids = [int(v) for v in rng.choice(np.arange(1, 91), size=20, replace=False)] if rng.integers(0, 2) else None
+        K = n + int(bg)
+        lut = host.remap_lut(best, bg, K, ids)
+        lab = np.arange(K, dtype=np.float32)
+        ref = OP.remap_labels(lab, best, bg, ids)
+        assert lut == [int(v) for v in ref], (best, bg, ids)
+    words = ["cat", "dog", "aeroplane", "pottedplant", "tvmonitor", "diningtable", "bus", "refrigerator"]
+    from pnp_ovss.tokenizer import SynthTokenizer
+    tok = SynthTokenizer(2048)
+    for _ in range(200):
+        names = [words[i] for i in rng.integers(0, len(words), size=int(rng.integers(1, 7)))]
+        pieces = tok.tokenize(" ".join(names))
+        ours = host.merge_plan(pieces, len(names))
+        ref = OP.merge_plan(pieces, len(names))
+        if ref is None:
+            assert ours == [([i], 1) for i in range(len(names))]
+        else:
+            assert ours == ref, (names, pieces)
