@@ -189,6 +189,36 @@ int pnp_preprocess_images(const uint8_t* d_rgb, const pnp_pre_image* d_desc, int
                           const int32_t* d_coef, uint8_t* d_tmp, const float* mean3, const float* std3, float* d_out,
                           void* stream);
 
+/* Dataset.py:349-445 / PnP.py:929-955 `Image.open(path).convert('RGB')` on device, for baseline (sequential Huffman, 8-bit,
+ * grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0) JPEG files: Pillow = libjpeg(-turbo) defaults, restated bit-exactly (islow
+ * integer IDCT, fancy chroma upsampling, fixed-point YCbCr -> RGB).  The host parses the markers (pnp_ovss/jpeg.py) and
+ * hands over the entropy-coded bytes, the tables and these descriptors; one wave decodes one restart segment of one
+ * image, so the batch is the parallelism.  Output: the images' RGB bytes (H*W*3, HWC) at rgb_off -- the buffer
+ * pnp_preprocess_images and pnp_post_batch.d_rgb read.  *d_err is set to 1 on a corrupt stream.  Stateless. */
+typedef struct pnp_jpeg_image {
+    int64_t data_off;           /* offset of the entropy-coded segment in d_data, a multiple of 16 */
+    int64_t coef_off[3];        /* int16 elements: quantised coefficient blocks [blocks_y][blocks_x][64] per component */
+    int64_t plane_off[3];       /* bytes: component sample planes, row stride blocks_x * 8 */
+    int64_t rgb_off;            /* bytes */
+    int32_t data_len, H, W, ncomp, hmax, vmax, mcux, mcuy;
+    int32_t h[3], v[3], tq[3], td[3], ta[3], bx[3], by[3];
+    int32_t tab, pad[2];
+} pnp_jpeg_image;
+typedef struct pnp_jpeg_tables {
+    uint16_t fast[4][256];      /* [DC0, DC1, AC0, AC1][next 8 bits] = (code length << 8) | symbol; 0: code longer than 8 bits */
+    int32_t mincode[4][17], maxcode[4][17], valptr[4][17];     /* ITU T.81 F.2.2.3 */
+    uint8_t vals[4][256];
+    int32_t quant[4][64];       /* natural (row-major) order */
+} pnp_jpeg_tables;
+typedef struct pnp_jpeg_segment {
+    int64_t byte_off;           /* first byte of the restart interval, relative to data_off */
+    int32_t image, mcu0, nmcu, pad;
+} pnp_jpeg_segment;
+int pnp_jpeg_decode(const uint8_t* d_data, const pnp_jpeg_image* d_images, const pnp_jpeg_tables* d_tables,
+                    const pnp_jpeg_segment* d_segments, int32_t n_images, int32_t n_segments, int16_t* d_coef, int64_t coef_elems,
+                    uint8_t* d_planes, uint8_t* d_rgb, int32_t max_blocks_per_image, int32_t max_pixels_per_image, int32_t* d_err,
+                    void* stream);
+
 /* ---- introspection (tests / profiling) --------------------------------------------------- */
 /* Named internal device buffers: "image_embeds" (fp32 B*N*D), "maps" (fp32 post-process maps),
  * "crf_q", "P", "dP", "crf_M" (int32 [2][B+1] lattice id bases), ... */

@@ -66,6 +66,7 @@ def get_args_parser():
     p.add_argument("--crf_chunk", default=0, type=int, help="images per DenseCRF launch group (0 = the whole batch)")
     p.add_argument("--checkpoint", default=None, help="BLIP ITM-large checkpoint (.pth); default: seeded synthetic weights")
     p.add_argument("--vocab", default=None, help="bert-base-uncased vocab.txt")
+    p.add_argument("--device_jpeg", default=1, type=int, help="1: decode JPEG files on the GPU (baseline files; others fall back to Pillow)")
     p.add_argument("--synthetic_images", default=70, type=int)
     p.add_argument("--max_batches", default=0, type=int)
     return p

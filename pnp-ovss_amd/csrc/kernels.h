@@ -89,6 +89,30 @@ int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int l
 int confusion_hist(const uint8_t* labels, const float* gt, const PostDesc* desc, const size_t* label_off,
                    unsigned long long* hist, int n_class, int B, int maxHW, hipStream_t s);
 
+// jpeg.hip -- descriptors shared with the host (pnp_ovss/jpeg.py mirrors them with ctypes; see include/pnp_hip.h)
+struct JpegImage {
+    int64_t data_off;       // offset of the entropy-coded segment in d_data (16-byte aligned)
+    int64_t coef_off[3];    // int16 elements: component coefficient blocks [blocks_y][blocks_x][64], natural order
+    int64_t plane_off[3];   // bytes: component sample planes, row stride blocks_x * 8
+    int64_t rgb_off;        // bytes: output RGB, H * W * 3
+    int32_t data_len, H, W, ncomp, hmax, vmax, mcux, mcuy;
+    int32_t h[3], v[3], tq[3], td[3], ta[3], bx[3], by[3];
+    int32_t tab, pad[2];
+};
+struct JpegTables {
+    uint16_t fast[4][256];  // [DC0, DC1, AC0, AC1][next 8 bits] = (code length << 8) | symbol, 0 = longer than 8 bits
+    int32_t mincode[4][17], maxcode[4][17], valptr[4][17];      // ITU T.81 F.2.2.3
+    uint8_t vals[4][256];
+    int32_t quant[4][64];   // natural (row-major) order
+};
+struct JpegSegment {
+    int64_t byte_off;       // first entropy-coded byte of the restart interval, relative to the image's data_off
+    int32_t image, mcu0, nmcu, pad;
+};
+int jpeg_decode(const uint8_t* d_data, const JpegImage* d_imgs, const JpegTables* d_tabs, const JpegSegment* d_segs, int n_images,
+                int n_segments, int16_t* d_coef, size_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb, int max_blocks, int max_pixels,
+                int* d_err, hipStream_t s);
+
 // crf.hip
 size_t crf_sort_temp_bytes(size_t max_entries, int max_images);
 int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,

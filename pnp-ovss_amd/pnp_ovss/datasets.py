@@ -2,6 +2,8 @@
 deliver to the driver (`img0`, `img_id`, original RGB for the CRF, ground-truth label map), sharded
 across ranks like `DataLoader(..., sampler=DistributedSampler(dataset))` (Load_datasets.py:15-26).
 
+JPEG files are decoded on the device per batch (hip.jpeg_decode_batch -> csrc/jpeg.hip: Pillow-exact baseline decoder;
+`--device_jpeg 0` or a file the decoder does not cover -> Pillow on the host); PNG ground truth stays on the host.
   synthetic  seeded images + one-word-piece-per-class captions (no files needed; bench / CI)
   voc        Dataset.py:349-445 (bicubic resize to img_size, CLIP mean/std: on device, bit-identical to the
              Pillow / torchvision host path -- pnp_preprocess_images), PnP.py:901-955 (GT / RGB)
@@ -57,6 +59,37 @@ class _Base:
 
     resample = ("bicubic", synth.CLIP_MEAN, synth.CLIP_STD)      # Dataset.py:434-443
 
+    def _decode_on_device(self, items):
+        """Items whose image is still a JPEG byte string are decoded together on the GPU; a file the device decoder does
+        not cover (progressive, arithmetic, CMYK) is decoded by Pillow on the host, loudly."""
+        todo = [k for k, it in enumerate(items) if isinstance(it[2], (bytes, bytearray))]
+        if not todo:
+            return items
+        import io
+        import warnings
+        from . import hip
+        from .jpeg import UnsupportedJpeg
+        items = [list(it) for it in items]
+        good = []
+        for k in todo:
+            try:
+                from . import jpeg as J
+                J.parse(items[k][2])
+                good.append(k)
+            except UnsupportedJpeg as exc:
+                from PIL import Image
+                warnings.warn(f"image {items[k][1]}: {exc}: decoded on the host")
+                items[k][2] = np.asarray(Image.open(io.BytesIO(items[k][2])).convert("RGB"))
+        if good:
+            dec = hip.jpeg_decode_batch([items[k][2] for k in good])
+            for k, t in zip(good, dec):
+                items[k][2] = t
+        if any(isinstance(it[2], np.ndarray) for it in items) and any(isinstance(it[2], torch.Tensor) for it in items):
+            for it in items:                                       # mixed batch: everything onto the device
+                if isinstance(it[2], np.ndarray):
+                    it[2] = torch.from_numpy(np.ascontiguousarray(it[2])).cuda()
+        return [tuple(it) for it in items]
+
     def batches(self, batch_size):
         """Items whose first element is None get their model tensor from the device-side resize + normalise
         (hip.preprocess_images: Pillow-exact, Dataset.py:434-443 / :1263) over the decoded RGB the CRF uses anyway."""
@@ -74,6 +107,7 @@ class _Base:
         for o in range(0, len(idx), batch_size):
             ids = idx[o:o + batch_size]
             items = list(pool.map(self.__getitem__, ids)) if pool else [self[i] for i in ids]
+            items = self._decode_on_device(items)
             if items[0][0] is None:
                 from . import hip
                 filt, mean, std = self.resample
@@ -82,6 +116,20 @@ class _Base:
                 imgs = torch.stack([it[0] for it in items])
             yield {"imgs": imgs, "img_ids": [it[1] for it in items],
                    "org_images": [it[2] for it in items], "label_trues": [it[3] for it in items]}
+
+
+def _read_rgb(path, device_jpeg):
+    """The image as the datasets hand it on: the JPEG file's bytes when the batch is decoded on the device
+    (hip.jpeg_decode_batch), else `Image.open(path).convert('RGB')` as a numpy array (Dataset.py:349-445)."""
+    if device_jpeg and path.lower().endswith((".jpg", ".jpeg")):
+        with open(path, "rb") as f:
+            return f.read()
+    from PIL import Image
+    return np.asarray(Image.open(path).convert("RGB"))
+
+
+def _device_jpeg(args):
+    return bool(getattr(args, "device_jpeg", True)) and torch.cuda.is_available()
 
 
 class SyntheticDataset(_Base):
@@ -138,8 +186,7 @@ class VocLikeDataset(_Base):
     def __getitem__(self, i):
         from PIL import Image
         img_id = self.ids[i]
-        img = Image.open(os.path.join(self.img_dir, img_id + ".jpg")).convert("RGB")     # JPEG decode stays on the host
-        org = np.asarray(img)
+        org = _read_rgb(os.path.join(self.img_dir, img_id + ".jpg"), _device_jpeg(self.args))    # bytes -> decoded per batch on the GPU
         gt = np.float32(Image.open(os.path.join(self.gt_dir, img_id + ".png")))
         if self.kind == "voc":
             gt[gt == 255] = 0                                    # PnP.py:908
@@ -174,7 +221,7 @@ class Ade20kDataset(_Base):
         img_id = rec["fpath_img"].split(".")[0].split("/")[-1].split("_")[-1].lstrip("0")     # Dataset.py:1270
         stem = "ADE_val_" + img_id.rjust(8, "0")
         home = self.args.home_dir
-        org = np.asarray(Image.open(f"{home}/ADEChallengeData2016/images/validation/{stem}.jpg").convert("RGB"))
+        org = _read_rgb(f"{home}/ADEChallengeData2016/images/validation/{stem}.jpg", _device_jpeg(self.args))
         gt = np.float32(Image.open(f"{home}/ADEChallengeData2016/annotations/validation/{stem}.png"))      # PnP.py:917-923
         return None, img_id, org, gt
 
@@ -223,7 +270,7 @@ class CocoDataset(_Base):
         from . import coco_mask
         rec = self.images[i]
         home = self.args.home_dir
-        org = np.asarray(Image.open(f"{home}/coco/images/val2017/{rec['file_name']}").convert("RGB"))
+        org = _read_rgb(f"{home}/coco/images/val2017/{rec['file_name']}", _device_jpeg(self.args))
         if self.kind == "coco_object":                            # PnPc.py:1099-1110: first annotation wins a pixel
             gt = np.zeros((rec["height"], rec["width"]), dtype=np.float32)
             for a in self.anns.get(rec["id"], []):

@@ -87,6 +87,7 @@ def load_library():
         "pnp_preprocess_images": (i32, [vp, vp, i32, i32, i32, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
         "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
         "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
+        "pnp_jpeg_decode": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp, vp, i32, i32, vp, vp]),
         "pnp_op_split": (i32, [vp, vp, vp, i64, vp]),
         "pnp_op_gemm_x3": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
         "pnp_dbg_gemm_stamps": (i32, [vp, i32]),
@@ -107,7 +108,7 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images",
             "pnp_cross_kv", "pnp_profile_read_stage", "pnp_op_split", "pnp_op_gemm_x3",
             "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer", "pnp_allocated_bytes",
-            "pnp_op_vit_attention_x3"]
+            "pnp_op_vit_attention_x3", "pnp_jpeg_decode"]
 
 
 class _DevView:
@@ -202,7 +203,12 @@ def preprocess_images(images, S, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), devi
         desc[i] = PnpPreImage(src_off, tmp_off, H, W, kx[0], kx[1], ky[0], ky[1])
         src_off += H * W * 3
         tmp_off += H * S * 3
-    rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(im, dtype=np.uint8).reshape(-1) for im in images])).to(dev)
+    if all(isinstance(im, torch.Tensor) for im in images):      # already on the device (pnp_jpeg_decode output)
+        rgb = torch.cat([im.reshape(-1) for im in images]) if len(images) > 1 else images[0].reshape(-1)
+        assert rgb.is_cuda and rgb.dtype == torch.uint8
+    else:
+        rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(im.cpu().numpy() if isinstance(im, torch.Tensor) else im,
+                                                                    dtype=np.uint8).reshape(-1) for im in images])).to(dev)
     coef = torch.from_numpy(np.concatenate(coef_parts)).to(dev)
     d_desc = torch.frombuffer(bytearray(bytes(desc)), dtype=torch.uint8).to(dev)
     tmp = torch.empty(tmp_off, dtype=torch.uint8, device=dev)
@@ -213,6 +219,40 @@ def preprocess_images(images, S, mean=(0.0, 0.0, 0.0), std=(1.0, 1.0, 1.0), devi
                                   tmp.data_ptr(), m3, s3, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     if r != 0:
         raise RuntimeError(f"pnp_preprocess_images failed ({r})")
+    return out
+
+
+def jpeg_decode_batch(files, device=None):
+    """`Image.open(f).convert('RGB')` for a batch of baseline JPEG byte strings, on the device (pnp_jpeg_decode): returns a
+    list of uint8 device tensors (H, W, 3), views of one concatenated buffer in batch order -- the layout the resize
+    kernel and the CRF read.  Raises pnp_ovss.jpeg.UnsupportedJpeg for progressive / arithmetic / CMYK files (the caller
+    decodes those with Pillow) and RuntimeError for a corrupt stream."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("pnp_ovss.hip.jpeg_decode_batch needs a HIP device (no CPU fallback)")
+    from . import jpeg as J
+    lib = load_library()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    data, imgs, tabs, segs, sizes, tot = J.pack_batch(files)
+
+    def up(buf):
+        return torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(dev)
+    d_data = torch.from_numpy(data).to(dev)
+    d_imgs, d_tabs, d_segs = up(imgs), up(tabs), up(segs)
+    d_coef = torch.empty(tot["coef_elems"], dtype=torch.int16, device=dev)
+    d_planes = torch.empty(tot["plane_bytes"], dtype=torch.uint8, device=dev)
+    d_rgb = torch.empty(tot["rgb_bytes"], dtype=torch.uint8, device=dev)
+    d_err = torch.zeros(1, dtype=torch.int32, device=dev)
+    r = lib.pnp_jpeg_decode(d_data.data_ptr(), d_imgs.data_ptr(), d_tabs.data_ptr(), d_segs.data_ptr(), len(files), len(segs),
+                            d_coef.data_ptr(), tot["coef_elems"], d_planes.data_ptr(), d_rgb.data_ptr(), tot["max_blocks"],
+                            tot["max_pixels"], d_err.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if r != 0:
+        raise RuntimeError(f"pnp_jpeg_decode failed ({r})")
+    if int(d_err.item()):
+        raise RuntimeError("pnp_jpeg_decode: corrupt entropy-coded data")
+    out, o = [], 0
+    for h, w in sizes:
+        out.append(d_rgb[o:o + h * w * 3].view(h, w, 3))
+        o += h * w * 3
     return out
 
 

@@ -299,7 +299,11 @@ class Segmenter:
             plans.append(host.merge_plan(pieces, len(best)))
             luts.append(host.remap_lut(best, bg, len(best) + int(bg), self.class_ids))
             bgs.append(bg)
-        rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(x, dtype=np.uint8).reshape(-1) for x in org_images])).to(dev)
+        if all(isinstance(x, torch.Tensor) and x.is_cuda for x in org_images):      # decoded on the device (hip.jpeg_decode_batch)
+            rgb = torch.cat([x.reshape(-1) for x in org_images])
+        else:
+            rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(x.cpu().numpy() if isinstance(x, torch.Tensor) else x,
+                                                                        dtype=np.uint8).reshape(-1) for x in org_images])).to(dev)
         gt = None
         if label_trues is not None:
             gt = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in label_trues])).to(dev)

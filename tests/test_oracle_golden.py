@@ -365,3 +365,79 @@ def test_crf_oracle_vs_pydensecrf_fixture(golden_dir):
         tie = (srt[-1] - srt[-2]) < 1e-3                      # Eigen's exp vs include/pnp_math.h: near-tie tolerant
         assert ((lab != g[f"labels_{i}"]) & ~tie).sum() == 0, i
         assert np.abs(q - ref_q).max() < 5e-3, i
+
+
+# ------------------------------------------------------------------------------------------ JPEG input (f-1)
+
+def jpeg_cases():
+    """Seeded JPEG byte strings covering what the datasets ship and the corner cases of the decoder: sizes that are not
+    multiples of the MCU, 4:4:4 / 4:2:2 / 4:2:0, qualities 40..98, optimised Huffman tables, restart intervals,
+    grayscale.  Encoded with Pillow at test time (the fixture is the generator, the expected pixels are Pillow's own)."""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    out = []
+
+    def img(h, w, kind):
+        if kind == "blocks":
+            rgb, _ = synth.synth_images(1, max(h, w) + 8, seed=h * 1000 + w, noise=10)
+            return rgb[0, :h, :w]
+        if kind == "ramp":
+            yy, xx = np.mgrid[0:h, 0:w]
+            return np.stack([(xx * 3 + yy) % 256, (yy * 2) % 256, (xx + yy * 5) % 256], -1).astype(np.uint8)
+        return rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    specs = [((48, 64), "blocks", 75, 2, {}), ((37, 53), "ramp", 90, 2, {}), ((100, 75), "noise", 50, 2, {}),
+             ((8, 8), "blocks", 95, 0, {}), ((17, 9), "noise", 40, 1, {}), ((64, 33), "ramp", 98, 0, {}),
+             ((120, 160), "blocks", 85, 2, {"optimize": True}), ((90, 123), "noise", 70, 2, {"restart_marker_blocks": 3}),
+             ((75, 100), "blocks", 80, 1, {"restart_marker_rows": 1}), ((33, 47), "ramp", 60, 2, {}), ((375, 500), "blocks", 92, 2, {})]
+    for (h, w), kind, q, ss, kw in specs:
+        buf = io.BytesIO()
+        Image.fromarray(img(h, w, kind)).save(buf, format="JPEG", quality=q, subsampling=ss, **kw)
+        out.append(buf.getvalue())
+    buf = io.BytesIO()
+    Image.fromarray(img(40, 56, "blocks")[..., 0]).save(buf, format="JPEG", quality=85)          # grayscale
+    out.append(buf.getvalue())
+    return out
+
+
+def test_jpeg_oracle_matches_pillow():
+    """oracle/jpeg_np.py (Huffman decode, islow IDCT, fancy upsampling, fixed-point YCbCr -> RGB restated from the published
+    libjpeg algorithm) against Pillow's own `Image.open(...).convert('RGB')`: bit-exact."""
+    import io
+    from PIL import Image
+    from oracle import jpeg_np as J
+    for data in jpeg_cases()[:10] + jpeg_cases()[11:]:           # (the 375 x 500 case is for the device test: slow in Python)
+        ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        np.testing.assert_array_equal(J.decode(data), ref)
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(buf, format="JPEG", progressive=True)
+    with pytest.raises(J.JpegError):
+        J.decode(buf.getvalue())
+
+
+def test_jpeg_host_packing_matches_oracle_parser():
+    """pnp_ovss.jpeg (the product's marker walk + device table builder) against the oracle's parser: geometry, tables,
+    restart segments; unsupported flavours are refused loudly."""
+    import io
+    from PIL import Image
+    from pnp_ovss import jpeg as PJ
+    from oracle import jpeg_np as J
+    files = jpeg_cases()
+    data, imgs, tabs, segs, sizes, tot = PJ.pack_batch(files)
+    assert len(imgs) == len(files) and tot["rgb_bytes"] == sum(h * w * 3 for h, w in sizes)
+    for i, f in enumerate(files):
+        j = J.parse_jpeg(f)
+        assert (imgs[i].H, imgs[i].W) == (j["frame"]["H"], j["frame"]["W"]) == sizes[i]
+        assert imgs[i].data_off % 16 == 0 and imgs[i].data_len == len(j["scan"])
+        assert bytes(data[imgs[i].data_off:imgs[i].data_off + imgs[i].data_len]) == j["scan"]
+        for ci, c in enumerate(j["frame"]["comps"]):
+            np.testing.assert_array_equal(np.array(tabs[i].quant[c["tq"]][:]), j["qt"][c["tq"]])
+            _, mincode, maxcode, valptr = J.huff_lookup(*j["ht"][(1, c["ta"])])
+            assert list(tabs[i].mincode[2 + c["ta"]][1:]) == mincode[1:] and list(tabs[i].maxcode[2 + c["ta"]][1:]) == maxcode[1:]
+    nseg = [sum(1 for s in segs if s.image == i) for i in range(len(files))]
+    assert nseg[7] > 1 and nseg[8] > 1 and nseg[0] == 1                        # the two restart-interval files are split
+    assert sum(s.nmcu for s in segs if s.image == 7) == imgs[7].mcux * imgs[7].mcuy
+    buf = io.BytesIO()
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8)).save(buf, format="JPEG", progressive=True)
+    with pytest.raises(PJ.UnsupportedJpeg):
+        PJ.pack_batch([buf.getvalue()])
