@@ -98,7 +98,9 @@ def test_voc_dataset_device_preprocess_equals_host_pillow_path(tmp_path):
             img = Image.open(root / "JPEGImages" / f"{name}.jpg").convert("RGB")
             x = np.asarray(img.resize((64, 64), Image.BICUBIC), dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
             assert np.array_equal(got[j], (x - mean) / std), name
-            assert np.array_equal(b["org_images"][j], np.asarray(img))
+            org = b["org_images"][j]
+            assert isinstance(org, torch.Tensor) and org.is_cuda              # decoded on the device (hip.jpeg_decode_batch)
+            assert np.array_equal(org.cpu().numpy(), np.asarray(img))
             assert b["label_trues"][j].dtype == np.float32 and b["label_trues"][j][0, 0] == 0      # 255 -> 0 (PnP.py:908)
 
 
