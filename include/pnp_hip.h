@@ -192,9 +192,13 @@ int pnp_preprocess_images(const uint8_t* d_rgb, const pnp_pre_image* d_desc, int
 /* Dataset.py:349-445 / PnP.py:929-955 `Image.open(path).convert('RGB')` on device, for baseline (sequential Huffman, 8-bit,
  * grayscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0) JPEG files: Pillow = libjpeg(-turbo) defaults, restated bit-exactly (islow
  * integer IDCT, fancy chroma upsampling, fixed-point YCbCr -> RGB).  The host parses the markers (pnp_ovss/jpeg.py) and
- * hands over the entropy-coded bytes, the tables and these descriptors; one wave decodes one restart segment of one
- * image, so the batch is the parallelism.  Output: the images' RGB bytes (H*W*3, HWC) at rgb_off -- the buffer
- * pnp_preprocess_images and pnp_post_batch.d_rgb read.  *d_err is set to 1 on a corrupt stream.  Stateless. */
+ * hands over the entropy-coded bytes, the file's own DHT / DQT tables and these descriptors.  Entropy decode: one workgroup
+ * per restart segment; the segment is cut into up to 1024 sub-sequences decoded by one thread each from a guessed decoder
+ * state, then re-decoded from the predecessor's exit state until no entry state changes (Huffman streams self-synchronise;
+ * the fixed point IS the sequential decode), block counts and DC differences are prefix-summed and a last pass writes the
+ * coefficients.  Output: the images' RGB bytes (H*W*3, HWC) at rgb_off -- the buffer pnp_preprocess_images and
+ * pnp_post_batch.d_rgb read.  Workspaces: d_clean (sum of clean_cap bytes: the un-stuffed streams), d_seg_bits (n_segments
+ * ints).  *d_err is set to 1 on a corrupt or truncated stream.  Stateless. */
 typedef struct pnp_jpeg_image {
     int64_t data_off;           /* offset of the entropy-coded segment in d_data, a multiple of 16 */
     int64_t coef_off[3];        /* int16 elements: quantised coefficient blocks [blocks_y][blocks_x][64] per component */
@@ -205,19 +209,23 @@ typedef struct pnp_jpeg_image {
     int32_t tab, pad[2];
 } pnp_jpeg_image;
 typedef struct pnp_jpeg_tables {
-    uint16_t fast[4][256];      /* [DC0, DC1, AC0, AC1][next 8 bits] = (code length << 8) | symbol; 0: code longer than 8 bits */
-    int32_t mincode[4][17], maxcode[4][17], valptr[4][17];     /* ITU T.81 F.2.2.3 */
-    uint8_t vals[4][256];
+    uint8_t counts[4][16];      /* [DC0, DC1, AC0, AC1]: DHT code counts per length 1..16 ... */
+    uint8_t vals[4][256];       /* ... and symbols, as in the file (the look-ahead tables are built on the device) */
     int32_t quant[4][64];       /* natural (row-major) order */
 } pnp_jpeg_tables;
 typedef struct pnp_jpeg_segment {
     int64_t byte_off;           /* first byte of the restart interval, relative to data_off */
-    int32_t image, mcu0, nmcu, pad;
+    int64_t clean_off;          /* offset of its un-stuffed copy in d_clean, a multiple of 16 */
+    int32_t image, mcu0, nmcu;
+    int32_t raw_len;            /* entropy-coded bytes of the interval, markers excluded */
+    int32_t clean_cap;          /* bytes reserved at clean_off, >= raw_len + 32 */
+    int32_t sub_bits;           /* sub-sequence length in bits: a multiple of 32, >= 8 * raw_len / 1024 */
+    int32_t pad[2];
 } pnp_jpeg_segment;
 int pnp_jpeg_decode(const uint8_t* d_data, const pnp_jpeg_image* d_images, const pnp_jpeg_tables* d_tables,
-                    const pnp_jpeg_segment* d_segments, int32_t n_images, int32_t n_segments, int16_t* d_coef, int64_t coef_elems,
-                    uint8_t* d_planes, uint8_t* d_rgb, int32_t max_blocks_per_image, int32_t max_pixels_per_image, int32_t* d_err,
-                    void* stream);
+                    const pnp_jpeg_segment* d_segments, int32_t n_images, int32_t n_segments, uint8_t* d_clean, int32_t* d_seg_bits,
+                    int16_t* d_coef, int64_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb, int32_t max_blocks_per_image,
+                    int32_t max_pixels_per_image, int32_t* d_err, void* stream);
 
 /* ---- introspection (tests / profiling) --------------------------------------------------- */
 /* Named internal device buffers: "image_embeds" (fp32 B*N*D), "maps" (fp32 post-process maps),

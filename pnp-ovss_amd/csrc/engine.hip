@@ -1539,15 +1539,17 @@ extern "C" int pnp_preprocess_images(const uint8_t* d_rgb, const pnp_pre_image* 
 }
 
 extern "C" int pnp_jpeg_decode(const uint8_t* d_data, const pnp_jpeg_image* d_images, const pnp_jpeg_tables* d_tables,
-                               const pnp_jpeg_segment* d_segments, int32_t n_images, int32_t n_segments, int16_t* d_coef,
-                               int64_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb, int32_t max_blocks_per_image,
-                               int32_t max_pixels_per_image, int32_t* d_err, void* stream) {
-    if (!d_data || !d_images || !d_tables || !d_segments || !d_coef || !d_planes || !d_rgb || !d_err || coef_elems <= 0) return PNP_ERR_ARG;
+                               const pnp_jpeg_segment* d_segments, int32_t n_images, int32_t n_segments, uint8_t* d_clean,
+                               int32_t* d_seg_bits, int16_t* d_coef, int64_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb,
+                               int32_t max_blocks_per_image, int32_t max_pixels_per_image, int32_t* d_err, void* stream) {
+    if (!d_data || !d_images || !d_tables || !d_segments || !d_clean || !d_seg_bits || !d_coef || !d_planes || !d_rgb || !d_err ||
+        coef_elems <= 0)
+        return PNP_ERR_ARG;
     static_assert(sizeof(pnp_jpeg_image) == sizeof(JpegImage) && sizeof(pnp_jpeg_tables) == sizeof(JpegTables) &&
                       sizeof(pnp_jpeg_segment) == sizeof(JpegSegment), "JPEG descriptor layouts are part of the ABI");
     return jpeg_decode(d_data, reinterpret_cast<const JpegImage*>(d_images), reinterpret_cast<const JpegTables*>(d_tables),
-                       reinterpret_cast<const JpegSegment*>(d_segments), n_images, n_segments, d_coef, (size_t)coef_elems, d_planes,
-                       d_rgb, max_blocks_per_image, max_pixels_per_image, d_err, (hipStream_t)stream);
+                       reinterpret_cast<const JpegSegment*>(d_segments), n_images, n_segments, d_clean, d_seg_bits, d_coef,
+                       (size_t)coef_elems, d_planes, d_rgb, max_blocks_per_image, max_pixels_per_image, d_err, (hipStream_t)stream);
 }
 
 extern "C" int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream) {

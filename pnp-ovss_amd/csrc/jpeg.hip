@@ -2,15 +2,20 @@
 // with Pillow on the main thread (Dataset.py:349-445 `Image.open(...).convert('RGB')`, PnP_OVSS_0514_updated_
 // segmentation.py:929-955 load_OrgImage; DataLoader num_workers = 0).  Pillow's arithmetic is libjpeg(-turbo)'s defaults,
 // an un-vendored library, restated from its published algorithm (oracle/jpeg_np.py, pinned bit-exact against Pillow):
-//   jpeg_huffman_kernel  sequential Huffman entropy decode (ITU T.81 F.2.2), ONE WAVE PER RESTART SEGMENT of an image:
-//                        the bit stream is inherently serial, the parallelism is the batch (35 images per step) --
-//                        byte-stuffed stream staged through an LDS ring by all 64 lanes, 8-bit look-ahead code tables
-//                        in LDS, every lane runs the same (uniform) decode, lane 0 stores quantised coefficients
+//   jpeg_unstuff_kernel  one workgroup per restart segment: drops the 0x00 that follows every 0xFF of the entropy-coded
+//                        bytes (block-wide compaction), so the decoder reads plain big-endian words
+//   jpeg_huffman_kernel  Huffman entropy decode (ITU T.81 F.2.2), one workgroup of 1024 threads per restart segment.  The
+//                        bit stream is serial only in its decoder STATE (bit position, block-in-MCU, zig-zag index), and
+//                        Huffman streams self-synchronise: the segment is cut into up to 1024 sub-sequences of equal
+//                        bit length, every thread decodes its own from a guessed state, then repeatedly takes over the
+//                        exit state of its predecessor and re-decodes until no entry state changes (a fixed point of
+//                        S[i+1] = f(S[i]) with S[0] known is the sequential decode; typically 2-4 rounds).  Block counts and
+//                        DC differences per sub-sequence are prefix-summed, and a last pass writes the coefficients.
+//                        Look-ahead tables (10 bits) are built in LDS from the file's own DHT bytes.
 //   jpeg_idct_kernel     one thread per 8 x 8 block: dequantise + jidctint.c "islow" (13-bit constants, DESCALE)
 //   jpeg_color_kernel    one thread per pixel: jdsample.c "fancy" h2v1 / h2v2 chroma upsampling + jdcolor.c fixed-point
 //                        YCbCr -> RGB, written as the concatenated HWC uint8 buffer the resize and the CRF read
-// Integer / byte work, HBM-trivial (a 500 x 375 image: ~100 KB in, 0.56 MB out); the entropy decode is latency-bound
-// (~100 clk per symbol, a few ms per image) and overlaps the previous batch's model work on the prefetch stream.
+// Integer / byte work, HBM-trivial (a 500 x 375 image: ~85 KB in, 0.56 MB out).
 #include "common.h"
 #include "kernels.h"
 
@@ -20,149 +25,298 @@ __constant__ int kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 
                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-constexpr int JPEG_RING = 16384;      // LDS bytes of stream staged at a time (two halves of 8 KB)
+constexpr int JPEG_T = 1024;          // threads = sub-sequences per restart segment
+constexpr int JPEG_LA = 10;           // look-ahead bits of the code tables
+constexpr int JPEG_MAXB = 6;          // blocks per MCU (4:2:0)
+
+// exclusive prefix sum over the workgroup (tid order); wsum: one int per wave
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();                                      // wsum may still be read from the previous scan
+    if (lane == 63) wsum[w] = x;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+        if (i < w) off += wsum[i];
+        tot += wsum[i];
+    }
+    if (total) *total = tot;
+    return off + x - v;
+}
+
+// ------------------------------------------------------------------------------------------ byte un-stuffing
+__global__ __launch_bounds__(256) void jpeg_unstuff_kernel(const uint8_t* __restrict__ data, const JpegImage* __restrict__ imgs,
+                                                           const JpegSegment* __restrict__ segs, uint8_t* __restrict__ clean,
+                                                           int* __restrict__ seg_bits) {
+    __shared__ int wsum[4];
+    const JpegSegment sg = segs[blockIdx.x];
+    const uint8_t* src = data + imgs[sg.image].data_off + sg.byte_off;
+    uint8_t* dst = clean + sg.clean_off;
+    const int n = sg.raw_len, tid = threadIdx.x;
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 256 * 16) {
+        const int o = c0 + tid * 16;
+        uint8_t b[16];
+        unsigned keep = 0;
+        int prev = (o > 0 && o <= n) ? src[o - 1] : 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const bool in = o + j < n;
+            b[j] = in ? src[o + j] : 0;
+            if (in && !(b[j] == 0 && prev == 0xFF)) keep |= 1u << j;
+            prev = b[j];
+        }
+        int total;
+        int w = base + block_excl_scan(__popc(keep), wsum, &total);
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+            if (keep >> j & 1) dst[w++] = b[j];
+        base += total;
+    }
+    // zeros behind the data (what libjpeg feeds after the end), up to the capacity the host reserved
+    for (int i = base + tid; i < sg.clean_cap; i += 256) dst[i] = 0;
+    if (tid == 0) seg_bits[blockIdx.x] = base * 8;
+}
 
 // ------------------------------------------------------------------------------------------ entropy decode
-__global__ __launch_bounds__(64) void jpeg_huffman_kernel(const uint8_t* __restrict__ data, const JpegImage* __restrict__ imgs,
-                                                          const JpegTables* __restrict__ tabs, const JpegSegment* __restrict__ segs,
-                                                          int16_t* __restrict__ coef, int* __restrict__ err) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring[JPEG_RING];
-    __shared__ uint16_t fast[4][256];
-    __shared__ int mincode[4][17], maxcode[4][17], valptr[4][17];
-    __shared__ uint8_t vals[4][256];
-    __shared__ int zz[64];
-    const JpegSegment sg = segs[blockIdx.x];
-    const JpegImage* const ip = imgs + sg.image;        // per-component fields are read through memory (runtime index)
-    const JpegImage im = *ip;
-    const JpegTables& T = tabs[im.tab];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 4 * 256; i += 64) {
-        (&fast[0][0])[i] = (&T.fast[0][0])[i];
-        (&vals[0][0])[i] = (&T.vals[0][0])[i];
-    }
-    for (int i = lane; i < 4 * 17; i += 64) {
-        (&mincode[0][0])[i] = (&T.mincode[0][0])[i];
-        (&maxcode[0][0])[i] = (&T.maxcode[0][0])[i];
-        (&valptr[0][0])[i] = (&T.valptr[0][0])[i];
-    }
-    zz[lane] = kZigzag[lane];
-    const uint8_t* src = data + im.data_off;
-    const long end = im.data_len;
-    long fill = sg.byte_off & ~(long)15;       // stream bytes [fill - JPEG_RING, fill) are in the ring (position p at p % RING)
-    // cooperative refill of one 8 KB half starting at stream offset `from` (16-byte aligned)
-    auto refill = [&](long from) {
-#pragma unroll
-        for (int i = 0; i < JPEG_RING / 2 / 16 / 64; i++) {
-            const long o = from + (long)(i * 64 + lane) * 16;
-            chunk16 v = {0u, 0u, 0u, 0u};
-            if (o + 16 <= end) {
-                v = *reinterpret_cast<const chunk16*>(src + o);           // data_off is 16-byte aligned by the host
-            } else if (o < end) {
-                uint8_t tmp[16];
-                for (int b = 0; b < 16; b++) tmp[b] = o + b < end ? src[o + b] : 0;
-                v = *reinterpret_cast<const chunk16*>(tmp);
-            }
-            *reinterpret_cast<chunk16*>(ring + (o & (JPEG_RING - 1))) = v;
-        }
-    };
-    refill(fill);
-    refill(fill + JPEG_RING / 2);
-    fill += JPEG_RING;
-    __syncthreads();
+struct JpegLds {
+    uint16_t fast[4][1 << JPEG_LA];
+    int mincode[4][17], maxcode[4][17], valptr[4][17];
+    uint8_t vals[4][256];
+    int zz[64];
+    int mb_info[JPEG_MAXB], mb_by[JPEG_MAXB], mb_bx[JPEG_MAXB];      // per block of the MCU: component | DC table << 2 | AC table << 4
+    int g_h[3], g_v[3], g_bxc[3];
+    long g_coef[3];
+    unsigned Ep[JPEG_T];
+    uint16_t Ebk[JPEG_T];
+    int Ecnt[JPEG_T], Edc[3][JPEG_T];
+    int wsum[JPEG_T / 64];
+    int done;
+};
 
-    long p = sg.byte_off;                       // next stream byte to enter the bit buffer
-    uint64_t acc = 0;                           // valid bits at the top
-    int nbits = 0;
-    bool hit_marker = false;
-    auto fill_bits = [&]() {                    // keep >= 32 valid bits (zeros past a marker / the end, like libjpeg)
-        while (nbits <= 56) {
-            if (p >= fill - JPEG_RING / 2) {    // the read position has left the older half of the ring: recycle that half
-                __syncthreads();
-                refill(fill);
-                fill += JPEG_RING / 2;
-                __syncthreads();
-            }
-            unsigned b = 0;
-            if (!hit_marker && p < end) {
-                b = ring[p & (JPEG_RING - 1)];
-                if (b == 0xFF) {
-                    const unsigned n = p + 1 < end ? ring[(p + 1) & (JPEG_RING - 1)] : 0xD9;
-                    if (n == 0) p += 2;
-                    else { hit_marker = true; b = 0; }
-                } else {
-                    p += 1;
+struct JpegGeom {            // uniform per workgroup
+    int bpm, mcux, mcu0, total_blocks;
+};
+
+__device__ __forceinline__ uint32_t jpeg_word(const uint32_t* __restrict__ w, uint32_t i) { return __builtin_bswap32(w[i]); }
+
+// Decode from state (p, b, k) up to the first code boundary at or behind p_end.  WRITE = false: only the exit state, the
+// number of blocks completed and the sum of DC differences per component (the synchronisation rounds).  WRITE = true: n is the
+// index of the block in progress, pred the DC predictors at the entry; coefficients go to global memory.
+template <bool WRITE>
+__device__ __forceinline__ void jpeg_run(const JpegLds& S, const JpegGeom& G, const uint32_t* __restrict__ words, unsigned& p, int& b,
+                                         int& k, unsigned p_end, int& cnt, int& dc0, int& dc1, int& dc2, int n, int16_t* __restrict__ coef,
+                                         int* __restrict__ err, int* done) {
+    uint32_t wp = p >> 5;
+    uint64_t acc = ((uint64_t)jpeg_word(words, wp) << 32) | jpeg_word(words, wp + 1);
+    const int sh = p & 31;
+    acc <<= sh;
+    int nb = 64 - sh;
+    wp += 2;
+    uint32_t nxt = jpeg_word(words, wp);                 // one word ahead of the bit buffer (hides the load latency)
+    int16_t* blk = nullptr;
+    auto block_ptr = [&](int nblk, int bi) -> int16_t* {
+        const int mcu = G.mcu0 + nblk / G.bpm;
+        const int my = mcu / G.mcux, mx = mcu - my * G.mcux;
+        const int c = S.mb_info[bi] & 3;
+        return coef + S.g_coef[c] + ((long)(my * S.g_v[c] + S.mb_by[bi]) * S.g_bxc[c] + (mx * S.g_h[c] + S.mb_bx[bi])) * 64;
+    };
+    if (WRITE) blk = block_ptr(n, b);
+    int info = S.mb_info[b];
+    while (p < p_end) {
+        if (nb < 32) {
+            acc |= (uint64_t)nxt << (32 - nb);
+            nb += 32;
+            wp++;
+            nxt = jpeg_word(words, wp);
+        }
+        const int c = info & 3;
+        const int t = k == 0 ? (info >> 2) & 1 : 2 + ((info >> 4) & 1);
+        const unsigned top = (unsigned)(acc >> 48);
+        const unsigned f = S.fast[t][top >> (16 - JPEG_LA)];
+        int len = f >> 8, sym = f & 255;
+        if (len == 0) {                                  // code longer than the look-ahead: T.81 F.2.2.3 scan
+            len = 16;
+            sym = 0;
+            bool found = false;
+            for (int l = JPEG_LA + 1; l <= 16; l++) {
+                const int code = (int)(top >> (16 - l));
+                if (S.maxcode[t][l] >= 0 && code <= S.maxcode[t][l] && code >= S.mincode[t][l]) {
+                    len = l;
+                    sym = S.vals[t][(S.valptr[t][l] + code - S.mincode[t][l]) & 255];
+                    found = true;
+                    break;
                 }
             }
-            acc |= (uint64_t)b << (56 - nbits);
-            nbits += 8;
+            if (WRITE && !found) atomicExch(err, 1);
         }
-    };
-    auto take = [&](int n) -> unsigned {        // n <= 16 bits off the top
-        const unsigned v = n ? (unsigned)(acc >> (64 - n)) : 0u;
-        acc <<= n;
-        nbits -= n;
-        return v;
-    };
-    auto symbol = [&](int t) -> int {
-        if (nbits < 32) fill_bits();
-        const unsigned f = fast[t][acc >> 56];
-        if (f >> 8) {
-            take(f >> 8);
-            return f & 255;
-        }
-        int code = (int)(acc >> 55);            // 9 bits
-        for (int l = 9; l <= 16; l++) {
-            if (maxcode[t][l] >= 0 && code <= maxcode[t][l] && code >= mincode[t][l]) {
-                take(l);
-                return vals[t][valptr[t][l] + code - mincode[t][l]];
+        const int s = sym & 15, r = k == 0 ? 0 : sym >> 4;
+        if (WRITE && k == 0 && sym > 11) atomicExch(err, 1);
+        acc <<= len;
+        const unsigned vb = s ? (unsigned)(acc >> (64 - s)) : 0u;
+        acc <<= s;
+        nb -= len + s;
+        p += len + s;
+        const int v = (s == 0 || vb >= (1u << (s - 1))) ? (int)vb : (int)vb - (1 << s) + 1;
+        if (k == 0) {
+            dc0 += c == 0 ? v : 0;                       // (selects, not an indexed array: that would live in scratch)
+            dc1 += c == 1 ? v : 0;
+            dc2 += c == 2 ? v : 0;
+            if (WRITE) blk[0] = (int16_t)(c == 0 ? dc0 : (c == 1 ? dc1 : dc2));
+            k = 1;
+        } else if (s == 0) {
+            k = r == 15 ? k + 16 : 64;
+        } else {
+            k += r;
+            if (k > 63) {
+                if (WRITE) atomicExch(err, 1);
+            } else if (WRITE) {
+                blk[S.zz[k]] = (int16_t)v;
             }
-            code = (int)(acc >> (64 - l - 1));
+            k++;
         }
-        if (lane == 0) atomicExch(err, 1);
-        take(16);
-        return 0;
-    };
-    auto extend = [](int v, int t) { return (t == 0 || v >= (1 << (t - 1))) ? v : v - (1 << t) + 1; };
+        if (k >= 64) {
+            k = 0;
+            b = b + 1 == G.bpm ? 0 : b + 1;
+            info = S.mb_info[b];
+            cnt++;
+            if (WRITE) {
+                n++;
+                if (n >= G.total_blocks) {
+                    *done = 1;
+                    break;
+                }
+                blk = block_ptr(n, b);
+            }
+        }
+    }
+}
 
-    int pred0 = 0, pred1 = 0, pred2 = 0;          // DC predictors (named: a runtime-indexed array would live in scratch)
-    for (int m = sg.mcu0; m < sg.mcu0 + sg.nmcu; m++) {
-        const int my = m / im.mcux, mx = m - my * im.mcux;
-        for (int c = 0; c < im.ncomp; c++) {
-            const int tdc = ip->td[c], tac = 2 + ip->ta[c], vc = ip->v[c], hc = ip->h[c], bxc = ip->bx[c];
-            const long coff = ip->coef_off[c];
-            for (int by = 0; by < vc; by++)
-                for (int bx = 0; bx < hc; bx++) {
-                    int16_t* blk = coef + coff + ((long)(my * vc + by) * bxc + (mx * hc + bx)) * 64;
-                    const int t = symbol(tdc);
-                    if (nbits < 32) fill_bits();
-                    const int diff = extend((int)take(t), t);
-                    int pc;
-                    if (c == 0) pc = (pred0 += diff);
-                    else if (c == 1) pc = (pred1 += diff);
-                    else pc = (pred2 += diff);
-                    if (lane == 0) blk[0] = (int16_t)pc;
-                    int k = 1;
-                    while (k < 64) {
-                        const int rs = symbol(tac);
-                        const int r = rs >> 4, s = rs & 15;
-                        if (s == 0) {
-                            if (r != 15) break;
-                            k += 16;
-                            continue;
-                        }
-                        k += r;
-                        if (nbits < 32) fill_bits();
-                        const int v = extend((int)take(s), s);
-                        if (k > 63) {
-                            if (lane == 0) atomicExch(err, 1);
-                            break;
-                        }
-                        if (lane == 0) blk[zz[k]] = (int16_t)v;
-                        k++;
+__global__ __launch_bounds__(JPEG_T) void jpeg_huffman_kernel(const uint8_t* __restrict__ clean, const JpegImage* __restrict__ imgs,
+                                                              const JpegTables* __restrict__ tabs, const JpegSegment* __restrict__ segs,
+                                                              const int* __restrict__ seg_bits, int16_t* __restrict__ coef,
+                                                              int* __restrict__ err) {
+    __shared__ JpegLds S;
+    const JpegSegment sg = segs[blockIdx.x];
+    const JpegImage* const ip = imgs + sg.image;
+    const JpegTables& T = tabs[ip->tab];
+    const int tid = threadIdx.x;
+    // canonical code ranges (one thread per table), then the look-ahead entries (all threads)
+    if (tid < 4) {
+        int code = 0, kk = 0;
+        for (int l = 1; l <= 16; l++) {
+            const int cnt = T.counts[tid][l - 1];
+            S.valptr[tid][l] = kk;
+            S.mincode[tid][l] = code;
+            code += cnt;
+            kk += cnt;
+            S.maxcode[tid][l] = cnt ? code - 1 : -1;
+            code <<= 1;
+        }
+    }
+    for (int i = tid; i < 4 * 256; i += JPEG_T) (&S.vals[0][0])[i] = (&T.vals[0][0])[i];
+    if (tid < 64) S.zz[tid] = kZigzag[tid];
+    JpegGeom G;
+    G.mcux = ip->mcux;
+    G.mcu0 = sg.mcu0;
+    const int ncomp = ip->ncomp;
+    int bpm = 0;
+    for (int c = 0; c < ncomp && c < 3; c++) {
+        const int hc = ip->h[c], vc = ip->v[c];
+        if (tid == 0) {
+            S.g_h[c] = hc;
+            S.g_v[c] = vc;
+            S.g_bxc[c] = ip->bx[c];
+            S.g_coef[c] = ip->coef_off[c];
+            for (int y = 0; y < vc; y++)
+                for (int x = 0; x < hc; x++) {
+                    const int bi = bpm + y * hc + x;
+                    if (bi < JPEG_MAXB) {
+                        S.mb_info[bi] = c | (ip->td[c] & 1) << 2 | (ip->ta[c] & 1) << 4;
+                        S.mb_by[bi] = y;
+                        S.mb_bx[bi] = x;
                     }
                 }
         }
+        bpm += hc * vc;
     }
+    G.bpm = bpm;
+    G.total_blocks = sg.nmcu * bpm;
+    if (bpm > JPEG_MAXB || ncomp > 3) {                   // the host refuses such files; never index past the per-block tables
+        if (tid == 0) atomicExch(err, 1);
+        return;
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 << JPEG_LA; i += JPEG_T) {
+        const int t = i >> JPEG_LA, x = i & ((1 << JPEG_LA) - 1);
+        unsigned e = 0;
+        for (int l = 1; l <= JPEG_LA; l++) {
+            const int code = x >> (JPEG_LA - l);
+            if (S.maxcode[t][l] >= 0 && code <= S.maxcode[t][l] && code >= S.mincode[t][l]) {
+                e = ((unsigned)l << 8) | S.vals[t][(S.valptr[t][l] + code - S.mincode[t][l]) & 255];
+                break;
+            }
+        }
+        S.fast[t][x] = (uint16_t)e;
+    }
+    if (tid == 0) S.done = 0;
+    __syncthreads();
+
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(clean + sg.clean_off);        // clean_off is 16-byte aligned
+    const unsigned total_bits = (unsigned)seg_bits[blockIdx.x];
+    const unsigned sub = (unsigned)sg.sub_bits;                                             // multiple of 32, >= total_bits / JPEG_T
+    const int nsub = (int)((total_bits + sub - 1) / sub);
+    const bool live = tid < nsub;
+    const unsigned p_end = live ? min((unsigned)(tid + 1) * sub, total_bits) : 0u;
+    // entry state of this sub-sequence: exact for thread 0, a guess (block start at the cut) for the others
+    unsigned sp = (unsigned)tid * sub;
+    int sb = 0, sk = 0;
+    bool dirty = live;
+    for (int round = 0; round <= JPEG_T; round++) {
+        if (dirty) {
+            unsigned p = sp;
+            int b = sb, k = sk, cnt = 0, d0 = 0, d1 = 0, d2 = 0;
+            jpeg_run<false>(S, G, words, p, b, k, p_end, cnt, d0, d1, d2, 0, nullptr, nullptr, nullptr);
+            S.Ep[tid] = p;
+            S.Ebk[tid] = (uint16_t)(b * 64 + k);
+            S.Ecnt[tid] = cnt;
+            S.Edc[0][tid] = d0;
+            S.Edc[1][tid] = d1;
+            S.Edc[2][tid] = d2;
+        }
+        __syncthreads();
+        dirty = false;
+        if (live && tid > 0) {
+            const unsigned np = S.Ep[tid - 1];
+            const int nbk = S.Ebk[tid - 1];
+            if (np != sp || nbk != sb * 64 + sk) {
+                sp = np;
+                sb = nbk >> 6;
+                sk = nbk & 63;
+                dirty = true;
+            }
+        }
+        if (!__syncthreads_or(dirty ? 1 : 0)) break;
+    }
+    // absolute block index and DC predictors at every entry state, then the writing pass
+    const int n0 = block_excl_scan(live ? S.Ecnt[tid] : 0, S.wsum, nullptr);
+    int p0 = block_excl_scan(live ? S.Edc[0][tid] : 0, S.wsum, nullptr);
+    int p1 = block_excl_scan(live ? S.Edc[1][tid] : 0, S.wsum, nullptr);
+    int p2 = block_excl_scan(live ? S.Edc[2][tid] : 0, S.wsum, nullptr);
+    if (live && n0 < G.total_blocks && sp < total_bits) {
+        unsigned p = sp;
+        int b = sb, k = sk, cnt = 0;
+        if (b != n0 % G.bpm) atomicExch(err, 1);
+        jpeg_run<true>(S, G, words, p, b, k, p_end, cnt, p0, p1, p2, n0, coef, err, &S.done);
+    }
+    __syncthreads();
+    if (tid == 0 && !S.done && G.total_blocks > 0) atomicExch(err, 1);       // the stream ended before the last block
 }
 
 // ------------------------------------------------------------------------------------------ inverse DCT
@@ -283,11 +437,12 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(const JpegImage* __rest
 
 // ------------------------------------------------------------------------------------------ host
 int jpeg_decode(const uint8_t* d_data, const JpegImage* d_imgs, const JpegTables* d_tabs, const JpegSegment* d_segs, int n_images,
-                int n_segments, int16_t* d_coef, size_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb, int max_blocks, int max_pixels,
-                int* d_err, hipStream_t s) {
+                int n_segments, uint8_t* d_clean, int* d_seg_bits, int16_t* d_coef, size_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb,
+                int max_blocks, int max_pixels, int* d_err, hipStream_t s) {
     if (n_images <= 0 || n_segments < n_images) return PNP_ERR_ARG;
     if (hipMemsetAsync(d_coef, 0, coef_elems * sizeof(int16_t), s) != hipSuccess) return PNP_ERR_HIP;
-    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3(n_segments), dim3(64), 0, s, d_data, d_imgs, d_tabs, d_segs, d_coef, d_err);
+    hipLaunchKernelGGL(jpeg_unstuff_kernel, dim3(n_segments), dim3(256), 0, s, d_data, d_imgs, d_segs, d_clean, d_seg_bits);
+    hipLaunchKernelGGL(jpeg_huffman_kernel, dim3(n_segments), dim3(JPEG_T), 0, s, d_clean, d_imgs, d_tabs, d_segs, d_seg_bits, d_coef, d_err);
     const int nb = (max_blocks + 255) / 256;
     hipLaunchKernelGGL(jpeg_idct_kernel, dim3(nb < 1 ? 1 : nb, n_images), dim3(256), 0, s, d_imgs, d_tabs, d_coef, d_planes);
     int np = (max_pixels + 255) / 256;

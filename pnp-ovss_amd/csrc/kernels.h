@@ -100,18 +100,22 @@ struct JpegImage {
     int32_t tab, pad[2];
 };
 struct JpegTables {
-    uint16_t fast[4][256];  // [DC0, DC1, AC0, AC1][next 8 bits] = (code length << 8) | symbol, 0 = longer than 8 bits
-    int32_t mincode[4][17], maxcode[4][17], valptr[4][17];      // ITU T.81 F.2.2.3
+    uint8_t counts[4][16];  // [DC0, DC1, AC0, AC1]: the file's DHT segments as they are (codes per length 1..16, symbols)
     uint8_t vals[4][256];
     int32_t quant[4][64];   // natural (row-major) order
 };
 struct JpegSegment {
     int64_t byte_off;       // first entropy-coded byte of the restart interval, relative to the image's data_off
-    int32_t image, mcu0, nmcu, pad;
+    int64_t clean_off;      // where its un-stuffed bytes go in d_clean (16-byte aligned)
+    int32_t image, mcu0, nmcu;
+    int32_t raw_len;        // entropy-coded bytes of the interval (markers excluded)
+    int32_t clean_cap;      // bytes reserved at clean_off: >= raw_len + 32
+    int32_t sub_bits;       // sub-sequence length of the parallel decode: a multiple of 32, >= 8 * raw_len / 1024
+    int32_t pad[2];
 };
 int jpeg_decode(const uint8_t* d_data, const JpegImage* d_imgs, const JpegTables* d_tabs, const JpegSegment* d_segs, int n_images,
-                int n_segments, int16_t* d_coef, size_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb, int max_blocks, int max_pixels,
-                int* d_err, hipStream_t s);
+                int n_segments, uint8_t* d_clean, int* d_seg_bits, int16_t* d_coef, size_t coef_elems, uint8_t* d_planes, uint8_t* d_rgb,
+                int max_blocks, int max_pixels, int* d_err, hipStream_t s);
 
 // crf.hip
 size_t crf_sort_temp_bytes(size_t max_entries, int max_images);

@@ -87,7 +87,7 @@ def load_library():
         "pnp_preprocess_images": (i32, [vp, vp, i32, i32, i32, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), vp, vp]),
         "pnp_op_layernorm": (i32, [vp, vp, vp, f32, i32, i32, vp, vp]),
         "pnp_op_cast": (i32, [i32, vp, vp, i64, vp]),
-        "pnp_jpeg_decode": (i32, [vp, vp, vp, vp, i32, i32, vp, i64, vp, vp, i32, i32, vp, vp]),
+        "pnp_jpeg_decode": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, i32, i32, vp, vp]),
         "pnp_op_split": (i32, [vp, vp, vp, i64, vp]),
         "pnp_op_gemm_x3": (i32, [vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
         "pnp_dbg_gemm_stamps": (i32, [vp, i32]),
@@ -238,12 +238,14 @@ def jpeg_decode_batch(files, device=None):
         return torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(dev)
     d_data = torch.from_numpy(data).to(dev)
     d_imgs, d_tabs, d_segs = up(imgs), up(tabs), up(segs)
+    d_clean = torch.empty(tot["clean_bytes"], dtype=torch.uint8, device=dev)
+    d_bits = torch.empty(len(segs), dtype=torch.int32, device=dev)
     d_coef = torch.empty(tot["coef_elems"], dtype=torch.int16, device=dev)
     d_planes = torch.empty(tot["plane_bytes"], dtype=torch.uint8, device=dev)
     d_rgb = torch.empty(tot["rgb_bytes"], dtype=torch.uint8, device=dev)
     d_err = torch.zeros(1, dtype=torch.int32, device=dev)
     r = lib.pnp_jpeg_decode(d_data.data_ptr(), d_imgs.data_ptr(), d_tabs.data_ptr(), d_segs.data_ptr(), len(files), len(segs),
-                            d_coef.data_ptr(), tot["coef_elems"], d_planes.data_ptr(), d_rgb.data_ptr(), tot["max_blocks"],
+                            d_clean.data_ptr(), d_bits.data_ptr(), d_coef.data_ptr(), tot["coef_elems"], d_planes.data_ptr(), d_rgb.data_ptr(), tot["max_blocks"],
                             tot["max_pixels"], d_err.data_ptr(), torch.cuda.current_stream().cuda_stream)
     if r != 0:
         raise RuntimeError(f"pnp_jpeg_decode failed ({r})")

@@ -26,12 +26,15 @@ class JpegImage(C.Structure):
 
 
 class JpegTables(C.Structure):
-    _fields_ = [("fast", (C.c_uint16 * 256) * 4), ("mincode", (C.c_int32 * 17) * 4), ("maxcode", (C.c_int32 * 17) * 4),
-                ("valptr", (C.c_int32 * 17) * 4), ("vals", (C.c_uint8 * 256) * 4), ("quant", (C.c_int32 * 64) * 4)]
+    _fields_ = [("counts", (C.c_uint8 * 16) * 4), ("vals", (C.c_uint8 * 256) * 4), ("quant", (C.c_int32 * 64) * 4)]
 
 
 class JpegSegment(C.Structure):
-    _fields_ = [("byte_off", C.c_int64), ("image", C.c_int32), ("mcu0", C.c_int32), ("nmcu", C.c_int32), ("pad", C.c_int32)]
+    _fields_ = [("byte_off", C.c_int64), ("clean_off", C.c_int64)] + \
+               [(n, C.c_int32) for n in ("image", "mcu0", "nmcu", "raw_len", "clean_cap", "sub_bits")] + [("pad", C.c_int32 * 2)]
+
+
+SUBSEQUENCES = 1024     # threads per restart segment of the device decoder (csrc/jpeg.hip JPEG_T)
 
 
 def _u16(b, p):
@@ -120,40 +123,35 @@ def parse(data: bytes):
 
 
 def _fill_tables(tab, j):
-    """Huffman tables in the device form: 8-bit look-ahead + canonical (mincode, maxcode, valptr) per T.81 F.2.2.3."""
+    """The file's DHT (code counts per length, symbols) and DQT tables as they are; the device builds its look-ahead tables
+    (T.81 F.2.2.3 canonical codes) from them."""
     for (tc, th), (counts, symbols) in j["ht"].items():
         if th > 1:
             continue
+        if sum(counts) > 256 or len(symbols) != sum(counts):
+            raise UnsupportedJpeg("bad Huffman table")
         t = tc * 2 + th
-        code, k = 0, 0
-        for l in range(1, 17):
-            tab.valptr[t][l] = k
-            tab.mincode[t][l] = code
-            for _ in range(counts[l - 1]):
-                if l <= 8:
-                    base = code << (8 - l)
-                    for x in range(1 << (8 - l)):
-                        tab.fast[t][base + x] = (l << 8) | symbols[k]
-                tab.vals[t][k] = symbols[k]
-                code += 1
-                k += 1
-            tab.maxcode[t][l] = code - 1 if counts[l - 1] else -1
-            code <<= 1
+        tab.counts[t][:] = counts
+        tab.vals[t][:len(symbols)] = symbols
     for tq, q in j["qt"].items():
         if tq < 4:
-            for i in range(64):
-                tab.quant[tq][i] = int(q[i])
+            tab.quant[tq][:] = q.tolist()
+
+
+def _table_key(j):
+    return (tuple(sorted((k, tuple(c), tuple(v)) for k, (c, v) in j["ht"].items())), tuple(sorted((k, q.tobytes()) for k, q in j["qt"].items())))
 
 
 def pack_batch(files):
     """list of JPEG byte strings -> (data uint8 array, JpegImage[], JpegTables[], JpegSegment[], sizes, totals) ready to
-    upload.  totals = dict(coef_elems, plane_bytes, rgb_bytes, max_blocks, max_pixels)."""
+    upload.  totals = dict(coef_elems, plane_bytes, rgb_bytes, clean_bytes, max_blocks, max_pixels).  Files with the same
+    DHT + DQT bytes (every file an encoder wrote with its default tables at one quality) share one JpegTables entry."""
     n = len(files)
     imgs = (JpegImage * n)()
-    tabs = (JpegTables * n)()
+    tab_index, tab_list = {}, []
     segs = []
     chunks, data_off = [], 0
-    coef = plane = rgb = 0
+    coef = plane = rgb = clean = 0
     max_blocks = max_pixels = 0
     sizes = []
     for i, f in enumerate(files):
@@ -177,32 +175,45 @@ def pack_batch(files):
             plane += nb * 64
             blocks += nb
         im.rgb_off = rgb
-        im.tab = i
+        key = _table_key(j)
+        if key not in tab_index:
+            tab_index[key] = len(tab_list)
+            t = JpegTables()
+            _fill_tables(t, j)
+            tab_list.append(t)
+        im.tab = tab_index[key]
         rgb += j["H"] * j["W"] * 3
         sizes.append((j["H"], j["W"]))
         max_blocks = max(max_blocks, blocks)
         max_pixels = max(max_pixels, j["H"] * j["W"])
-        _fill_tables(tabs[i], j)
         # restart intervals: every RSTn marker starts an independently decodable segment
         nmcu = mcux * mcuy
+        starts, ends = [0], []
         if j["dri"]:
             ff = np.flatnonzero(scan[:-1] == 0xFF)
             rst = ff[(scan[ff + 1] >= 0xD0) & (scan[ff + 1] <= 0xD7)]
-            starts = [0] + [int(p) + 2 for p in rst]
-            for k, s in enumerate(starts):
-                m0 = k * j["dri"]
-                if m0 >= nmcu:
-                    break
-                segs.append((s, i, m0, min(j["dri"], nmcu - m0)))
-        else:
-            segs.append((0, i, 0, nmcu))
+            starts += [int(p) + 2 for p in rst]
+            ends = [int(p) for p in rst]
+        ends.append(len(scan))
+        for k, (s0, s1) in enumerate(zip(starts, ends)):
+            m0 = k * j["dri"] if j["dri"] else 0
+            if m0 >= nmcu:
+                break
+            raw = s1 - s0
+            cap = ((raw + 15) & ~15) + 32
+            sub = max(128, (-(-raw * 8 // SUBSEQUENCES) + 31) & ~31)
+            segs.append((s0, clean, i, m0, min(j["dri"], nmcu - m0) if j["dri"] else nmcu, raw, cap, sub))
+            clean += cap
         chunks.append(scan)
         pad = (-len(scan)) % 16
         if pad:
             chunks.append(np.zeros(pad, dtype=np.uint8))
         data_off += len(scan) + pad
+    tabs = (JpegTables * len(tab_list))(*tab_list)
     sg = (JpegSegment * len(segs))()
-    for k, (off, i, m0, nm) in enumerate(segs):
-        sg[k].byte_off, sg[k].image, sg[k].mcu0, sg[k].nmcu = off, i, m0, nm
+    for k, (off, coff, i, m0, nm, raw, cap, sub) in enumerate(segs):
+        g = sg[k]
+        g.byte_off, g.clean_off, g.image, g.mcu0, g.nmcu, g.raw_len, g.clean_cap, g.sub_bits = off, coff, i, m0, nm, raw, cap, sub
     data = np.concatenate(chunks) if chunks else np.zeros(16, dtype=np.uint8)
-    return data, imgs, tabs, sg, sizes, dict(coef_elems=coef, plane_bytes=plane, rgb_bytes=rgb, max_blocks=max_blocks, max_pixels=max_pixels)
+    return data, imgs, tabs, sg, sizes, dict(coef_elems=coef, plane_bytes=plane, rgb_bytes=rgb, clean_bytes=clean, max_blocks=max_blocks,
+                                             max_pixels=max_pixels)

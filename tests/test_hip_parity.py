@@ -1017,9 +1017,10 @@ def test_postprocess_pair_equals_two_single_runs(data_type):
 
 
 def test_jpeg_decode_on_device_matches_pillow():
-    """f-1: `Image.open(f).convert('RGB')` on the device (pnp_jpeg_decode: batch-parallel Huffman decode, islow IDCT, fancy
-    chroma upsampling, fixed-point colour conversion) against Pillow itself, bit-exact, over odd sizes, every supported
-    sampling, restart intervals, optimised tables, grayscale and a VOC-sized image; and straight into the resize kernel."""
+    """f-1: `Image.open(f).convert('RGB')` on the device (pnp_jpeg_decode: self-synchronising parallel Huffman decode, islow
+    IDCT, fancy chroma upsampling, fixed-point colour conversion) against Pillow itself, bit-exact, over odd sizes, every
+    supported sampling, restart intervals, optimised tables, grayscale and a VOC-sized image; and straight into the resize
+    kernel."""
     import io
     from PIL import Image
     from pnp_ovss import hip
@@ -1030,6 +1031,27 @@ def test_jpeg_decode_on_device_matches_pillow():
     for f, t in zip(files, out):
         ref = np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))
         np.testing.assert_array_equal(t.cpu().numpy(), ref)
+    # streams that stress the parallel decode: white noise at quality 100 (long codes, ~7 bits per coefficient: the
+    # sub-sequences synchronise late), a flat image (a few bits per block: thousands of blocks per sub-sequence), a
+    # megapixel photo-like image with optimised tables and one with a restart interval per MCU row
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:768, 0:1024]
+    photo = np.stack([128 + 90 * np.sin(xx / 37.0 + yy / 91.0), 128 + 80 * np.cos(xx / 53.0 - yy / 29.0), (xx + 2 * yy) % 256], -1)
+    photo = np.clip(photo + rng.normal(0, 6, photo.shape), 0, 255).astype(np.uint8)
+    hard = []
+    for arr, kw in [(rng.integers(0, 256, (301, 403, 3), dtype=np.uint8), dict(quality=100, subsampling=0)),
+                    (np.full((512, 640, 3), 77, np.uint8), dict(quality=75)),
+                    (photo, dict(quality=93, optimize=True)), (photo[:500, :700], dict(quality=85, restart_marker_rows=1)),
+                    (rng.integers(0, 256, (64, 64, 3), dtype=np.uint8), dict(quality=30, subsampling=1))]:
+        buf = io.BytesIO()
+        Image.fromarray(arr).save(buf, format="JPEG", **kw)
+        hard.append(buf.getvalue())
+    out2 = hip.jpeg_decode_batch(hard)
+    for f, t in zip(hard, out2):
+        np.testing.assert_array_equal(t.cpu().numpy(), np.asarray(Image.open(io.BytesIO(f)).convert("RGB")))
+    # a truncated stream is an error, not a silently grey image
+    with pytest.raises(RuntimeError):
+        hip.jpeg_decode_batch([hard[2][:len(hard[2]) // 2] + b"\xff\xd9"])
     # the decoded buffer feeds the device resize + normalise without a host round trip
     got = hip.preprocess_images(out[:3], 32, synth.CLIP_MEAN, synth.CLIP_STD).cpu().numpy()
     mean = np.array(synth.CLIP_MEAN, dtype=np.float32).reshape(3, 1, 1)

@@ -430,10 +430,19 @@ def test_jpeg_host_packing_matches_oracle_parser():
         assert (imgs[i].H, imgs[i].W) == (j["frame"]["H"], j["frame"]["W"]) == sizes[i]
         assert imgs[i].data_off % 16 == 0 and imgs[i].data_len == len(j["scan"])
         assert bytes(data[imgs[i].data_off:imgs[i].data_off + imgs[i].data_len]) == j["scan"]
+        t = tabs[imgs[i].tab]
         for ci, c in enumerate(j["frame"]["comps"]):
-            np.testing.assert_array_equal(np.array(tabs[i].quant[c["tq"]][:]), j["qt"][c["tq"]])
-            _, mincode, maxcode, valptr = J.huff_lookup(*j["ht"][(1, c["ta"])])
-            assert list(tabs[i].mincode[2 + c["ta"]][1:]) == mincode[1:] and list(tabs[i].maxcode[2 + c["ta"]][1:]) == maxcode[1:]
+            np.testing.assert_array_equal(np.array(t.quant[c["tq"]][:]), j["qt"][c["tq"]])
+            counts, symbols = j["ht"][(1, c["ta"])]
+            assert list(t.counts[2 + c["ta"]]) == list(counts) and list(t.vals[2 + c["ta"]][:len(symbols)]) == list(symbols)
+    d2 = PJ.pack_batch([files[0], files[2], files[0]])                         # files with the same DHT + DQT bytes share an entry
+    assert len(d2[2]) == 2 and [im.tab for im in d2[1]] == [0, 1, 0]
+    clean_end = 0
+    for s in segs:                                                             # un-stuffed copies: disjoint, aligned, with slack
+        assert s.clean_off % 16 == 0 and s.clean_off >= clean_end and s.clean_cap >= s.raw_len + 32
+        assert s.sub_bits % 32 == 0 and s.sub_bits * PJ.SUBSEQUENCES >= s.raw_len * 8
+        clean_end = s.clean_off + s.clean_cap
+    assert clean_end == tot["clean_bytes"]
     nseg = [sum(1 for s in segs if s.image == i) for i in range(len(files))]
     assert nseg[7] > 1 and nseg[8] > 1 and nseg[0] == 1                        # the two restart-interval files are split
     assert sum(s.nmcu for s in segs if s.image == 7) == imgs[7].mcux * imgs[7].mcuy
