@@ -113,6 +113,27 @@ def main(rank, world_size, args):
         Path(f"{args.save_path}/{d}/").mkdir(parents=True, exist_ok=True)
     n_img = 0
     t_loop = time.perf_counter()
+    # Two batches in flight: the host half of batch i+1 (class lookup, tokenisation, merge plans, uploads) and the
+    # bookkeeping of batch i-1 (histogram read-back, .npy files, the per-batch line) run while the GPU works on batch i,
+    # so each batch accumulates into its own pair of confusion matrices.
+    hist_ring = [(torch.zeros_like(seg.hist_1drop), torch.zeros_like(seg.hist_ndrop), torch.cuda.Event()) for _ in range(2)]
+
+    def finish(job):
+        img_ids, layer, head, l1, ln, (h1d, hnd, done) = job
+        done.synchronize()
+        h1 = h1d.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
+        hn = hnd.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
+        first = img_ids[0]
+        if l1:                                  # the COCO driver skips the 1-drop branch when drop_iter >= 3 (PnPc.py:420,633)
+            np.save(f"{args.save_path}/hist_withfiltered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", h1)
+        if ln:
+            np.save(f"{args.save_path}/all_drop_hist_with_filtered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", hn)
+        print(img_ids[:3], f"layer {layer} head {head}", "miou filtered_caption",
+              host.scores_from_hist(h1)["Mean IoU"] if l1 else None,
+              "miou all_drop", host.scores_from_hist(hn)["Mean IoU"] if ln else None, flush=True)
+        return hn if ln else h1
+
+    pending, slot = None, 0
     for bi, batch in enumerate(prefetch(ds.batches(args.batch_size), depth=2)):
         if args.max_batches and bi >= args.max_batches:
             break
@@ -121,24 +142,24 @@ def main(rank, world_size, args):
             b, names, cap = ds.predicted_classes(img_id)
             best.append(b)
             caps.append(cap)
+        prep = seg.prepare(caps, best, batch["org_images"], batch["label_trues"], batch.get("gt_dev"))
         for layer, head in pairs:
             pargs = argparse.Namespace(**{**vars(args), "max_att_block_num": layer, "prune_att_head": str(head)})
-            seg.hist_1drop.zero_()
-            seg.hist_ndrop.zero_()
-            l1, ln = seg.run(pargs, batch["imgs"], caps, best, batch["org_images"], batch["label_trues"], run_1drop=True)
-            torch.cuda.synchronize()
-            h1 = seg.hist_1drop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
-            hn = seg.hist_ndrop.cpu().numpy().reshape(n_class, n_class).astype(np.float64)
-            first = batch["img_ids"][0]
-            if l1 is not None:                  # the COCO driver skips the 1-drop branch when drop_iter >= 3 (PnPc.py:420,633)
-                np.save(f"{args.save_path}/hist_withfiltered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", h1)
-            if ln is not None:
-                np.save(f"{args.save_path}/all_drop_hist_with_filtered_caption/img_{first}_max_blocknum_{layer}_atthead_{head}.npy", hn)
-            print(batch["img_ids"][:3], f"layer {layer} head {head}", "miou filtered_caption",
-                  host.scores_from_hist(h1)["Mean IoU"] if l1 is not None else None,
-                  "miou all_drop", host.scores_from_hist(hn)["Mean IoU"] if ln is not None else None, flush=True)
+            ring = hist_ring[slot]
+            slot ^= 1
+            ring[0].zero_()
+            ring[1].zero_()
+            l1, ln = seg.launch(pargs, batch["imgs"], prep, run_1drop=True, hists=ring[:2])
+            ring[2].record()
+            job = (batch["img_ids"], layer, head, l1 is not None, ln is not None, ring)
+            if pending is not None:
+                last = finish(pending)          # the previous launch: long done, or at most the one before this one
+                if pending[0] is not batch["img_ids"]:
+                    ds.total_hist += last       # summary line: the last (layer, head) of a batch's sweep
+            pending = job
         n_img += len(batch["img_ids"])
-        ds.total_hist += hn if ln is not None else h1           # summary line: the last (layer, head) of the sweep
+    if pending is not None:
+        ds.total_hist += finish(pending)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_loop
     total = torch.from_numpy(ds.total_hist).to(torch.device("cuda", rank))

@@ -114,8 +114,13 @@ class _Base:
                 imgs = hip.preprocess_images([it[2] for it in items], self.args.img_size, mean, std, filt=filt)
             else:
                 imgs = torch.stack([it[0] for it in items])
-            yield {"imgs": imgs, "img_ids": [it[1] for it in items],
-                   "org_images": [it[2] for it in items], "label_trues": [it[3] for it in items]}
+            batch = {"imgs": imgs, "img_ids": [it[1] for it in items],
+                     "org_images": [it[2] for it in items], "label_trues": [it[3] for it in items]}
+            if torch.cuda.is_available() and all(it[3] is not None for it in items):
+                # the concatenated ground truth goes up here (this generator usually runs in the prefetch thread), not on
+                # the driver's critical path between the drop loop and the post-processing
+                batch["gt_dev"] = torch.from_numpy(np.concatenate([np.asarray(it[3], dtype=np.float32).reshape(-1) for it in items])).cuda()
+            yield batch
 
 
 def _read_rgb(path, device_jpeg):

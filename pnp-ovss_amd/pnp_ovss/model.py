@@ -282,14 +282,12 @@ class Segmenter:
         self.hist_1drop = torch.zeros(n_class * n_class, device=eng.device, dtype=torch.int64)
         self.hist_ndrop = torch.zeros(n_class * n_class, device=eng.device, dtype=torch.int64)
 
-    def run(self, args, imgs_in, captions, best_class_idx, org_images, label_trues, run_1drop=True):
-        m, eng = self.m, self.m.engine
-        dev = eng.device
+    def prepare(self, captions, best_class_idx, org_images, label_trues, gt_dev=None):
+        """Host-only half of a batch (no dependence on the model's results): tokenisation, word-piece merge plans, label
+        LUTs, the concatenated RGB / ground-truth buffers on the device.  A driver that pipelines batches calls this for
+        batch i+1 while the GPU still works on batch i."""
+        m, dev = self.m, self.m.engine.device
         tok500 = m.tokenizer(captions, padding="max_length", max_length=500, return_tensors="pt")
-        g0, agg = drop_loop(args, m, tok500, imgs_in, captions)
-        if self.coco and int(args.drop_iter) >= 3:
-            run_1drop = False
-        scale01 = (True, self.coco)                                 # Scale_0_1 on (1-drop, N-drop)
         ids = tok500.input_ids.numpy()
         sizes = [(int(x.shape[0]), int(x.shape[1])) for x in org_images]
         plans, luts, bgs = [], [], []
@@ -304,17 +302,33 @@ class Segmenter:
         else:
             rgb = torch.from_numpy(np.concatenate([np.ascontiguousarray(x.cpu().numpy() if isinstance(x, torch.Tensor) else x,
                                                                         dtype=np.uint8).reshape(-1) for x in org_images])).to(dev)
-        gt = None
-        if label_trues is not None:
+        gt = gt_dev
+        if gt is None and label_trues is not None:
             gt = torch.from_numpy(np.concatenate([np.asarray(x, dtype=np.float32).reshape(-1) for x in label_trues])).to(dev)
-        eng.post_prepare(sizes, plans, luts, bgs, rgb=rgb, gt=gt, want_crf=bool(self.mode and "crf" in self.mode))
+        return dict(tok500=tok500, captions=captions, sizes=sizes, plans=plans, luts=luts, bgs=bgs, rgb=rgb, gt=gt)
+
+    def launch(self, args, imgs_in, prep, run_1drop=True, hists=None):
+        """Device half: drop loop, merge, threshold / upsample, blur, CRF, argmax / remap, histogram into `hists`
+        (default: self.hist_1drop / self.hist_ndrop).  Returns the two label-map lists (views of engine buffers: valid
+        until the next launch); the tail of the work is still queued on the stream when this returns."""
+        m, eng = self.m, self.m.engine
+        h1, hn = hists if hists is not None else (self.hist_1drop, self.hist_ndrop)
+        g0, agg = drop_loop(args, m, prep["tok500"], imgs_in, prep["captions"])
+        if self.coco and int(args.drop_iter) >= 3:
+            run_1drop = False
+        scale01 = (True, self.coco)                                 # Scale_0_1 on (1-drop, N-drop)
+        eng.post_prepare(prep["sizes"], prep["plans"], prep["luts"], prep["bgs"], rgb=prep["rgb"], gt=prep["gt"],
+                         want_crf=bool(self.mode and "crf" in self.mode))
         out1 = outn = None
         if run_1drop and agg is not None and self.mode == "blur+crf":
             # both branches share the image lattices: one DenseCRF run over two channel groups (same results)
-            l1, ln = eng.postprocess_pair(g0, agg, self.threshold, self.n_class, self.hist_1drop, self.hist_ndrop, scale01)
+            l1, ln = eng.postprocess_pair(g0, agg, self.threshold, self.n_class, h1, hn, scale01)
             return eng.split_labels(l1), eng.split_labels(ln)
         if run_1drop or agg is None:
-            out1 = eng.split_labels(eng.postprocess(g0, self.threshold, scale01[0], self.mode, self.n_class, self.hist_1drop))
+            out1 = eng.split_labels(eng.postprocess(g0, self.threshold, scale01[0], self.mode, self.n_class, h1))
         if agg is not None:
-            outn = eng.split_labels(eng.postprocess(agg, self.threshold, scale01[1], self.mode, self.n_class, self.hist_ndrop))
+            outn = eng.split_labels(eng.postprocess(agg, self.threshold, scale01[1], self.mode, self.n_class, hn))
         return out1, outn
+
+    def run(self, args, imgs_in, captions, best_class_idx, org_images, label_trues, run_1drop=True, gt_dev=None):
+        return self.launch(args, imgs_in, self.prepare(captions, best_class_idx, org_images, label_trues, gt_dev), run_1drop)
