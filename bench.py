@@ -63,6 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercise launcher + rendezvous + broadcast / all-reduce / gather on CPU tensors")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # launcher test: this rank exits 3
+    ap.add_argument("--no-events", action="store_true", help="diagnostic: no hipEvents around the GEMM / CRF launches (no roofline records)")
+    ap.add_argument("--event-period", type=int, default=5,
+                    help="bracket every n-th launch of the dense GEMM family with hipEvents (5 is coprime to the 4-GEMM layer "
+                         "cycle: all shapes sampled equally; 1 = every launch, +2.3 %% step time)")
     ap.add_argument("--overlap", action="store_true",
                     help="software-pipeline batches over two HIP streams (drop loop of batch i+1 beside the post-process "
                          "of batch i); +2%% images/sec, off by default so the per-kernel event timing stays undisturbed")
@@ -313,7 +317,7 @@ def run_rank(a):
         run(warmup)
         sync()
         keep.clear()
-        e.profile_enable(True)
+        e.profile_enable(0 if a.no_events else max(1, a.event_period))
         t0 = time.perf_counter()
         run(steps)
         sync()
@@ -337,7 +341,8 @@ def run_rank(a):
                           "achieved counts ALGORITHMIC flops 2MNK, so the ceiling of frac is 1/3)"}[dtype]
         return {"bound": "mfma", "kernel": kern,
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+                "launches": launches, "sampling": f"every {max(1, a.event_period)}-th launch of the family bracketed by hipEvents",
+                "avg_launch_ms": ms / max(launches, 1),
                 "algorithmic_flop_per_launch": flops / max(launches, 1)}
 
     def roofline_crf(crf, steps, ppp):

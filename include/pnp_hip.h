@@ -235,7 +235,9 @@ int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, size_t* bytes)
  * kernel family (the dense NT GEMMs with M = B*N rows: gemm_nt_wide_kernel in bf16 mode,
  * gemm_nt_big_kernel<float> in fp32 mode) is bracketed by hipEvents on the launch stream.  pnp_profile_read
  * synchronises those events and returns launches, summed algorithmic FLOPs (2*M*N*K) and summed
- * kernel milliseconds since the last enable.  Off by default (no events on the hot path). */
+ * kernel milliseconds since the last enable.  Off by default (no events on the hot path).  on = 1 brackets every launch,
+ * on = n > 1 every n-th launch of the family (an event pair costs ~2.5 us of stream serialisation; sums cover the bracketed
+ * launches only). */
 int pnp_profile_enable(pnp_engine* e, int32_t on);
 int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms);
 /* Same for a pipeline stage: 0 = the dense GEMMs (as pnp_profile_read), 1 = the DenseCRF mean-field iterations

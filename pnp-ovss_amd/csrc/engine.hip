@@ -1411,6 +1411,8 @@ extern "C" int pnp_profile_enable(pnp_engine* e, int32_t on) {
     if (!e) return PNP_ERR_ARG;
     GemmProfile& pf = gemm_profile();
     pf.on = on != 0;
+    pf.period = on > 1 ? on : 1;
+    pf.seq = 0;
     pf.used = 0;
     pf.launches = 0;
     pf.flops = 0;

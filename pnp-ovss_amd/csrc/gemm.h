@@ -41,6 +41,8 @@ struct GemmProfile {
     static constexpr int kMax = 8192;
     hipEvent_t ev0[kMax], ev1[kMax];
     int created = 0, used = 0;
+    int period = 1;         // bracket every period-th launch
+    long long seq = 0;
     long long launches = 0;
     double flops = 0;
 };

@@ -496,7 +496,8 @@ class Engine:
 
     # ------------------------------------------------------------------ live kernel timing (bench roofline)
     def profile_enable(self, on=True):
-        self._chk(self.lib.pnp_profile_enable(self.h, 1 if on else 0), "pnp_profile_enable")
+        """on: False / True (every launch of the dense GEMM family bracketed by hipEvents) / n > 1 (every n-th launch)."""
+        self._chk(self.lib.pnp_profile_enable(self.h, int(on)), "pnp_profile_enable")
 
     def profile_read(self):
         n, fl, ms = C.c_int64(), C.c_double(), C.c_double()
