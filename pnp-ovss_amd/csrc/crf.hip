@@ -288,6 +288,12 @@ __global__ void crf_norm_kernel(const CrfLattice L, const PostDesc* __restrict__
     }
 }
 
+// contributor records get the normaliser of their pixel (the splat multiplies Q * norm before the barycentric weight)
+__global__ void entry_norm_kernel(CrfEntry* __restrict__ ent, size_t n, const float* __restrict__ norm) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        ent[i].nr = norm[ent[i].pixel];
+}
+
 // ------------------------------------------------------------------------------------------
 // Mean-field iteration kernels.  Values / Q / unary rows are padded to Kp = 4*ceil(K/4) floats so
 // every access is one 16-byte vector per lane (pad channels carry zeros and are never read back as
@@ -321,52 +327,122 @@ __device__ __forceinline__ bool xcd_work(int i, int xcd, int img0, int nimg, int
     return false;
 }
 
-// splat: val[id] = sum over the lattice point's contributors (ascending pixel) of bary * (Q * norm)
-template <int D1, int LPP>
-__global__ __launch_bounds__(256) void crf_splat4_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
-                                                         const float* __restrict__ Q, const float* __restrict__ norm,
-                                                         float* __restrict__ val, int img0, int nimg) {
+// splat: val[id] = sum over the lattice point's contributors (ascending pixel) of bary * (Q * norm).
+// LPP lanes share one lattice point (one 16-byte channel chunk each).  The contributor records of the point -- (pixel, bary,
+// norm) triples stored in list order by the lattice build -- are loaded LPP at a time, one 16-byte record per lane (one
+// coalesced load instead of a dependent index -> weight -> norm chain per contributor), handed round the group with lane
+// shuffles, and up to eight Q-row gathers are in flight per lane before the ordered accumulation.  The kernel is bound by
+// memory latency x occupancy, not by bytes, so the chain segment -> records -> rows is software-pipelined over the
+// grid-stride loop: while the rows of point t are gathered, the records of point t+1 and the segment of point t+2 are
+// already in flight (one exposed latency per point instead of three).  Per-channel arithmetic and order are those of the
+// sequential CPU algorithm (oracle/densecrf_ref.c::lattice_compute).  WHICH only names the instantiation in profiles.
+template <int LPP, int WHICH, bool MULTI>
+__global__ __launch_bounds__(256) void crf_splat_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
+                                                        const float* __restrict__ Q, float* __restrict__ val, int img0, int nimg) {
     constexpr int PPB = 256 / LPP;                       // lattice points per workgroup pass
+    constexpr int G = 8;                                 // row gathers in flight per lane
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
     const int c0 = threadIdx.x & (LPP - 1), pl = threadIdx.x / LPP;
+    const int stride = bpx * PPB;
+    const CrfEntry none = {0u, 0.f, 0.f, 0u};
     int b, part, parts;
     for (int wi = 0; xcd_work(wi, xcd, img0, nimg, b, part, parts); wi++) {
         const PostDesc im = imgs[b];
         const int K4 = im.Kp >> 2;
         const int lo = L.idbase[b], hi = L.idbase[b + 1];
-        const f32x4* Q4 = reinterpret_cast<const f32x4*>(Q + im.qoff);
+        // rows are addressed as base + 32-bit byte offset (an image's Q block is < 4 GB; pixels per image < 2^24)
+        const char* const Qb = reinterpret_cast<const char*>(Q + im.qoff);
+        const uint32_t rowb = (uint32_t)K4 * 16u;
         f32x4* V4 = reinterpret_cast<f32x4*>(val + im.voff[L.which]);
         const int r0 = (int)((long)(hi - lo) * part / parts), r1 = (int)((long)(hi - lo) * (part + 1) / parts);
-        for (int idl = r0 + slot * PPB + pl; idl < r1; idl += bpx * PPB) {
-            const int e0 = L.seg_lo[lo + idl], e1 = L.seg_hi[lo + idl];
-            for (int c = c0; c < K4; c += LPP) {
+        int idl = r0 + slot * PPB + pl;
+        // pipeline prologue: segment of points t and t+1, first record chunk of point t
+        int e0 = 0, e1 = 0, e0n = 0, e1n = 0;
+        if (idl < r1) {
+            e0 = L.seg_lo[lo + idl];
+            e1 = L.seg_hi[lo + idl];
+        }
+        if (idl + stride < r1) {
+            e0n = L.seg_lo[lo + idl + stride];
+            e1n = L.seg_hi[lo + idl + stride];
+        }
+        CrfEntry first = none;
+        if (c0 < e1 - e0) first = L.ent[e0 + c0];
+        f32x4 prev_acc = {0.f, 0.f, 0.f, 0.f};
+        size_t prev_at = 0;
+        bool have_prev = false;
+        // up to G row gathers of a record chunk (records j0 .. of `mine`, n valid), then their ordered accumulation
+        auto gather = [&](const CrfEntry& mine, int j0, int n, uint32_t cofs, f32x4* in) {
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if (j == 0 || j0 + j < n) {
+                    const uint32_t px = (uint32_t)__shfl((int)mine.pixel, j0 + j, LPP) - (uint32_t)im.pix0;
+                    in[j] = *reinterpret_cast<const f32x4*>(Qb + (__umul24(px, rowb) + cofs));
+                }
+            }
+        };
+        auto accumulate = [&](const CrfEntry& mine, int j0, int n, const f32x4* in, f32x4& acc) {
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                if (j == 0 || j0 + j < n) {
+                    const float w = __shfl(mine.w, j0 + j, LPP), nr = __shfl(mine.nr, j0 + j, LPP);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[i] = __fadd_rn(acc[i], __fmul_rn(w, __fmul_rn(in[j][i], nr)));
+                }
+            }
+        };
+        for (; idl < r1; idl += stride) {
+            // segment of point t+2 and first records of point t+1 are requested right behind the first gather group of point
+            // t (straight-line code, nothing pending in front of it), so the three latencies overlap: the compiler's wait in
+            // front of the accumulation covers them all
+            int e0nn = 0, e1nn = 0;
+            CrfEntry firstn = none;
+            auto prefetch = [&]() {
+                if (idl + 2 * stride < r1) {
+                    e0nn = L.seg_lo[lo + idl + 2 * stride];
+                    e1nn = L.seg_hi[lo + idl + 2 * stride];
+                }
+                if (c0 < e1n - e0n) firstn = L.ent[e0n + c0];
+            };
+            if (MULTI) prefetch();
+            // MULTI: rows wider than LPP chunks take several passes over the point's records (cb loop; the prefetch then sits
+            // in front of the loop and is waited for first); the common case is one straight-line pass
+            for (int cb = 0; cb < (MULTI ? K4 : 1); cb += LPP) {
+                const uint32_t cofs = (uint32_t)(cb + c0 < K4 ? cb + c0 : K4 - 1) * 16u;   // lanes past the row keep a valid chunk (they carry records)
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                for (int e = e0; e < e1; e += 4) {
-                    // issue up to four independent gathers before the ordered accumulation
-                    const int n = e1 - e;
-                    uint32_t pv[4];
-                    f32x4 in[4];
-                    float w[4], nr[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) pv[j] = L.vals[j < n ? e + j : e];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t pixel = pv[j] / (uint32_t)D1;
-                        in[j] = Q4[(size_t)(pixel - im.pix0) * K4 + c];
-                        nr[j] = norm[pixel];
-                        w[j] = L.bary[pv[j]];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if (j < n) {
-#pragma unroll
-                            for (int i = 0; i < 4; i++) acc[i] = __fadd_rn(acc[i], __fmul_rn(w[j], __fmul_rn(in[j][i], nr[j])));
-                        }
+                f32x4 in[G];
+                int n = e1 - e0 < LPP ? e1 - e0 : LPP;                    // (the same in all lanes of the group)
+                gather(first, 0, n, cofs, in);
+                if (!MULTI) {
+                    prefetch();
+                    if (have_prev) V4[prev_at] = prev_acc;                // the previous point's row, stored under this point's gathers
+                    asm volatile("" ::: "memory");                        // (keeps every request above in front of the wait below)
+                }
+                accumulate(first, 0, n, in, acc);
+                for (int j0 = G; j0 < n; j0 += G) {
+                    gather(first, j0, n, cofs, in);
+                    accumulate(first, j0, n, in, acc);
+                }
+                for (int eb = e0 + LPP; eb < e1; eb += LPP) {
+                    n = e1 - eb < LPP ? e1 - eb : LPP;
+                    const CrfEntry mine = c0 < n ? L.ent[eb + c0] : none;
+                    for (int j0 = 0; j0 < n; j0 += G) {
+                        gather(mine, j0, n, cofs, in);
+                        accumulate(mine, j0, n, in, acc);
                     }
                 }
-                V4[(size_t)idl * K4 + c] = acc;
+                if (MULTI) {
+                    if (cb + c0 < K4) V4[(size_t)idl * K4 + cb + c0] = acc;
+                } else {                                                  // stored one point later (a store waited for at the loop
+                    prev_acc = acc;                                       // head would expose its acknowledge latency)
+                    prev_at = (size_t)idl * K4 + c0;
+                    have_prev = c0 < K4;
+                }
             }
+            e0 = e0n; e1 = e1n; e0n = e0nn; e1n = e1nn;
+            first = firstn;
         }
+        if (have_prev) V4[prev_at] = prev_acc;
     }
 }
 
@@ -625,11 +701,16 @@ __global__ void renumber_entries_kernel(const int* __restrict__ rank, size_t n, 
 __global__ void seg_len_kernel(const int* __restrict__ seg_lo, const int* __restrict__ seg_hi, int M, int* __restrict__ len) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) len[i] = seg_hi[i] - seg_lo[i];
 }
-__global__ void move_segments_kernel(const uint32_t* __restrict__ vals, const int* __restrict__ new_start, int M,
-                                     int* __restrict__ seg_lo, int* __restrict__ seg_hi, uint32_t* __restrict__ vals2) {
+__global__ void move_segments_kernel(const uint32_t* __restrict__ vals, const int* __restrict__ new_start, int M, int D1,
+                                     const float* __restrict__ bary, int* __restrict__ seg_lo, int* __restrict__ seg_hi,
+                                     uint32_t* __restrict__ vals2, CrfEntry* __restrict__ ent) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
         const int a = seg_lo[i], n = seg_hi[i] - a, d = new_start[i];
-        for (int j = 0; j < n; j++) vals2[d + j] = vals[a + j];
+        for (int j = 0; j < n; j++) {
+            const uint32_t pv = vals[a + j];
+            vals2[d + j] = pv;
+            ent[d + j] = CrfEntry{pv / (uint32_t)D1, bary[pv], 0.f, 0u};  // the splat's contributor record (nr: crf_lattice_norm)
+        }
         seg_lo[i] = d;
         seg_hi[i] = d + n;
     }
@@ -705,7 +786,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     hipLaunchKernelGGL(seg_len_kernel, dim3(1024), dim3(256), 0, s, L.seg_lo, L.seg_hi, M, len);
     tb = temp_bytes;
     if (hipcub::DeviceScan::ExclusiveSum(temp, tb, len, incl, M, s) != hipSuccess) return PNP_ERR_HIP;
-    hipLaunchKernelGGL(move_segments_kernel, dim3(2048), dim3(256), 0, s, L.vals, incl, M, L.seg_lo, L.seg_hi, vals2);
+    hipLaunchKernelGGL(move_segments_kernel, dim3(2048), dim3(256), 0, s, L.vals, incl, M, D + 1, L.bary, L.seg_lo, L.seg_hi, vals2, L.ent);
     if (hipMemcpyAsync(L.vals, vals2, ent_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return PNP_ERR_HIP;
     return ok();
 }
@@ -713,7 +794,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
 static float crf_alpha(int D) { return 1.0f / (1 + powf(2, (float)-D)); }
 
 // norm = 1 / sqrt(lattice(ones) + 1e-20) for images [0,B); va/vb: scratch of >= (number of lattice points) floats.
-int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, float* va, float* vb,
+int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, size_t ent_total, float* va, float* vb,
                      float* norm_out, hipStream_t s) {
     const int D = L.D1 - 1;
     const int nb = 1024;
@@ -728,6 +809,7 @@ int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max
     }
     const int nbp = (max_pixels + 255) / 256 < 512 ? (max_pixels + 255) / 256 : 512;
     hipLaunchKernelGGL(crf_norm_kernel, dim3(nbp, B), dim3(256), 0, s, L, d_imgs, src, norm_out, crf_alpha(D));
+    hipLaunchKernelGGL(entry_norm_kernel, dim3(2048), dim3(256), 0, s, L.ent, ent_total, norm_out);
     return ok();
 }
 
@@ -737,16 +819,15 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
     const int D = L.D1 - 1;
     const int nb = 8 * 256;                                 // 8 XCD groups x 256 resident workgroups per XCD
     const int k4 = (max_kp + 3) / 4;
-#define PNP_SPLAT(D1_, LPP_) hipLaunchKernelGGL((crf_splat4_kernel<D1_, LPP_>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, norm, va, img0, nimg)
-    if (L.D1 == 3) {
-        if (k4 <= 8) PNP_SPLAT(3, 8);
-        else if (k4 <= 16) PNP_SPLAT(3, 16);
-        else PNP_SPLAT(3, 32);
-    } else {
-        if (k4 <= 8) PNP_SPLAT(6, 8);
-        else if (k4 <= 16) PNP_SPLAT(6, 16);
-        else PNP_SPLAT(6, 32);
-    }
+#define PNP_SPLAT(LPP_, MULTI_)                                                                                                  \
+    do {                                                                                                                      \
+        if (L.which == 0) hipLaunchKernelGGL((crf_splat_kernel<LPP_, 0, MULTI_>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg); \
+        else hipLaunchKernelGGL((crf_splat_kernel<LPP_, 1, MULTI_>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg);              \
+    } while (0)
+    if (k4 <= 8) PNP_SPLAT(8, false);
+    else if (k4 <= 16) PNP_SPLAT(16, false);
+    else if (k4 <= 32) PNP_SPLAT(32, false);
+    else PNP_SPLAT(32, true);
 #undef PNP_SPLAT
     float* src = va;
     float* dst = vb;

@@ -1035,6 +1035,7 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
         L.cap = cap;
         KCHK(e, dalloc(e, &L.bary, cap));
         KCHK(e, dalloc(e, &L.vals, cap));
+        KCHK(e, dalloc(e, &L.ent, cap));
         KCHK(e, dalloc(e, &L.offset, cap));
         KCHK(e, dalloc(e, &L.seg_start, cap + 1));
         KCHK(e, dalloc(e, &L.seg_lo, cap));
@@ -1190,7 +1191,7 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
             KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
                                       p.maxHW, p.seg_begin[t], p.seg_end[t], p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
                                       p.n1k, p.n2k, p.sort_tmp, p.sort_tmp_bytes, p.range_err, s));
-            KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.maxHW, p.va, p.vb, p.norm[t], s));
+            KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.maxHW, (size_t)pix * D1, p.va, p.vb, p.norm[t], s));
         }
         int err = 0;
         HIPCHK(e, hipMemcpyAsync(&err, p.range_err, 4, hipMemcpyDeviceToHost, s));

@@ -22,6 +22,15 @@ struct PostDesc {
     size_t voff[2];
 };
 
+// contributor record of a lattice point, stored in list order: global pixel index, barycentric weight, the pixel's
+// normaliser 1/sqrt(lattice(1) + 1e-20) (filled in by crf_lattice_norm); one 16-byte load per contributor
+struct alignas(16) CrfEntry {
+    uint32_t pixel;
+    float w;
+    float nr;
+    uint32_t pad;
+};
+
 // One permutohedral lattice type for a whole image batch (device pointers).
 struct CrfLattice {
     int D1;            // d + 1
@@ -29,6 +38,7 @@ struct CrfLattice {
     size_t cap;        // capacity (entries) = stride of the neighbour tables
     float* bary;       // [entries] barycentric weight per (pixel, vertex)
     uint32_t* vals;    // [entries] sorted (pixel, vertex) indices = contributor lists
+    CrfEntry* ent;     // [entries] the same lists as (pixel, weight, norm) records (what the splat streams)
     int* offset;       // [entries] lattice id per (pixel, vertex)
     int* seg_start;    // [M+1] first sorted entry of each lattice point, key order (build scratch)
     int* seg_lo;       // [M] contributor range of each lattice point (final, spatial numbering)
@@ -123,7 +133,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
                       int B, size_t ent_total, int max_pixels, const int* d_seg_begin, const int* d_seg_end,
                       uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
                       void* temp, size_t temp_bytes, int* d_range_err, hipStream_t s);
-int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, float* va, float* vb,
+int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, size_t ent_total, float* va, float* vb,
                      float* norm_out, hipStream_t s);
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
                float* va, float* vb, const float** result, int max_kp, hipStream_t s);
