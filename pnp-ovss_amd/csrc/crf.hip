@@ -502,41 +502,62 @@ __device__ __forceinline__ f32x4 crf_blur1(const f32x4& old, const f32x4& va, co
     for (int i = 0; i < 4; i++) o[i] = (float)__dadd_rn((double)old[i], __dmul_rn(0.5, (double)__fadd_rn(va[i], vd[i])));
     return o;
 }
+// The eight neighbour ids of a point for the axis pair (2p, 2p+1) come from one 32-byte record (CrfNbr8, image-local ids,
+// built once per lattice) instead of two dependent rounds of index loads; rows are addressed with 32-bit byte offsets; the
+// record of the thread's next item is requested behind the row gathers of the current one and the previous result is
+// stored there too, so an item exposes one memory latency (the kernel is bound by latency x occupancy and by the 64 B/clk
+// of the CU's vector memory path -- nine rows in, one out -- not by HBM bytes).
 __global__ __launch_bounds__(256) void crf_blur4x2_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs,
-                                                          const float* __restrict__ src, float* __restrict__ dst, int axis,
+                                                          const float* __restrict__ src, float* __restrict__ dst, int pair,
                                                           int img0, int nimg) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
-    const int* n1a = L.n1 + (size_t)axis * L.cap;
-    const int* n2a = L.n2 + (size_t)axis * L.cap;
-    const int* n1b = L.n1 + (size_t)(axis + 1) * L.cap;
-    const int* n2b = L.n2 + (size_t)(axis + 1) * L.cap;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int b, part, parts;
     for (int wi = 0; xcd_work(wi, xcd, img0, nimg, b, part, parts); wi++) {
         const PostDesc im = imgs[b];
         const int K4 = im.Kp >> 2;
         const int lo = L.idbase[b], hi = L.idbase[b + 1];
-        const f32x4* S4 = reinterpret_cast<const f32x4*>(src + im.voff[L.which]);
-        f32x4* D4 = reinterpret_cast<f32x4*>(dst + im.voff[L.which]);
+        const char* const Sb = reinterpret_cast<const char*>(src + im.voff[L.which]);
+        f32x4* const D4 = reinterpret_cast<f32x4*>(dst + im.voff[L.which]);
+        const CrfNbr8* const T = L.nbr8 + (size_t)pair * L.cap + lo;
+        const uint32_t rowb = (uint32_t)K4 * 16u;
         const int first = (int)((long)(hi - lo) * part / parts) * K4;
         const int nitem = (int)((long)(hi - lo) * (part + 1) / parts) * K4, stride = bpx * 256;
-        for (int it = first + slot * 256 + threadIdx.x; it < nitem; it += stride) {
-            const int p = it / K4, c = it - p * K4;
-            const int id = lo + p;
-            const int pa = n1b[id], pd = n2b[id];                  // axis+1 neighbours of the point
-            const int ia = n1a[id], idn = n2a[id];                 // axis neighbours of the point ...
-            const int aa = pa >= 0 ? n1a[pa] : -1, ad = pa >= 0 ? n2a[pa] : -1;      // ... and of its two axis+1 neighbours
-            const int da = pd >= 0 ? n1a[pd] : -1, dd = pd >= 0 ? n2a[pd] : -1;
-#define PNP_ROW(x) ((x) >= 0 ? S4[(size_t)((x) - lo) * K4 + c] : zero)
-            const f32x4 r_i = S4[it], r_ia = PNP_ROW(ia), r_id = PNP_ROW(idn);
-            const f32x4 r_a = PNP_ROW(pa), r_aa = PNP_ROW(aa), r_ad = PNP_ROW(ad);
-            const f32x4 r_d = PNP_ROW(pd), r_da = PNP_ROW(da), r_dd = PNP_ROW(dd);
+        const int sq = stride / K4, sr = stride - sq * K4;              // item -> (point, chunk) advances without a division
+        int it = first + slot * 256 + threadIdx.x;
+        int p = it / K4, c = it - p * K4;
+        CrfNbr8 t = {-1, -1, -1, -1, -1, -1, -1, -1};
+        if (it < nitem) t = T[p];
+        f32x4 prev = zero;
+        int prev_it = -1;
+        for (; it < nitem; it += stride) {
+            const uint32_t cofs = (uint32_t)c * 16u;
+#define PNP_ROW(x) ((x) >= 0 ? *reinterpret_cast<const f32x4*>(Sb + (__umul24((uint32_t)(x), rowb) + cofs)) : zero)
+            const f32x4 r_i = *reinterpret_cast<const f32x4*>(Sb + (__umul24((uint32_t)p, rowb) + cofs));
+            const f32x4 r_ia = PNP_ROW(t.ia), r_id = PNP_ROW(t.id);
+            const f32x4 r_a = PNP_ROW(t.pa), r_aa = PNP_ROW(t.aa), r_ad = PNP_ROW(t.ad);
+            const f32x4 r_d = PNP_ROW(t.pd), r_da = PNP_ROW(t.da), r_dd = PNP_ROW(t.dd);
 #undef PNP_ROW
+            // next item's neighbour record and the previous item's result go out behind the gathers
+            int pn = p + sq, cn = c + sr;
+            if (cn >= K4) {
+                cn -= K4;
+                pn++;
+            }
+            CrfNbr8 tn = {-1, -1, -1, -1, -1, -1, -1, -1};
+            if (it + stride < nitem) tn = T[pn];
+            if (prev_it >= 0) D4[prev_it] = prev;
+            asm volatile("" ::: "memory");
             const f32x4 m_i = crf_blur1(r_i, r_ia, r_id);
-            const f32x4 m_a = pa >= 0 ? crf_blur1(r_a, r_aa, r_ad) : zero;
-            const f32x4 m_d = pd >= 0 ? crf_blur1(r_d, r_da, r_dd) : zero;
-            D4[it] = crf_blur1(m_i, m_a, m_d);
+            const f32x4 m_a = t.pa >= 0 ? crf_blur1(r_a, r_aa, r_ad) : zero;
+            const f32x4 m_d = t.pd >= 0 ? crf_blur1(r_d, r_da, r_dd) : zero;
+            prev = crf_blur1(m_i, m_a, m_d);
+            prev_it = it;
+            t = tn;
+            p = pn;
+            c = cn;
         }
+        if (prev_it >= 0) D4[prev_it] = prev;
     }
 }
 
@@ -694,6 +715,35 @@ __global__ void renumber_entries_kernel(const int* __restrict__ rank, size_t n, 
         offset[i] = rank[offset[i]];
 }
 
+// ---- neighbour records of the two-axis blur: for axis pair (2p, 2p+1) the point's neighbours along axis 2p (ia, id), along
+// axis 2p+1 (pa, pd) and the axis-2p neighbours of those two (aa, ad, da, dd), as image-local ids (-1 = absent)
+__global__ void nbr8_kernel(const int* __restrict__ n1, const int* __restrict__ n2, size_t cap, const int* __restrict__ idbase,
+                            int npairs, CrfNbr8* __restrict__ out) {
+    const int b = blockIdx.y;
+    const int lo = idbase[b], hi = idbase[b + 1];
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (hi - lo) * npairs; t += gridDim.x * blockDim.x) {
+        const int id = lo + t / npairs, pr = t % npairs;
+        const int* n1a = n1 + (size_t)(2 * pr) * cap;
+        const int* n2a = n2 + (size_t)(2 * pr) * cap;
+        const int* n1b = n1 + (size_t)(2 * pr + 1) * cap;
+        const int* n2b = n2 + (size_t)(2 * pr + 1) * cap;
+        const int pa = n1b[id], pd = n2b[id];
+        CrfNbr8 r;
+        r.ia = n1a[id];
+        r.id = n2a[id];
+        r.pa = pa;
+        r.pd = pd;
+        r.aa = pa >= 0 ? n1a[pa] : -1;
+        r.ad = pa >= 0 ? n2a[pa] : -1;
+        r.da = pd >= 0 ? n1a[pd] : -1;
+        r.dd = pd >= 0 ? n2a[pd] : -1;
+        int* q = &r.ia;
+#pragma unroll
+        for (int k = 0; k < 8; k++) q[k] = q[k] >= 0 ? q[k] - lo : -1;
+        out[(size_t)pr * cap + id] = r;
+    }
+}
+
 // ---- contributor lists in lattice-id order.  The key sort leaves each point's contributor segment where its KEY
 // sorted; after the spatial renumbering consecutive lattice ids own segments scattered over the whole list.  The
 // segments are moved (each keeps its ascending-pixel order) so that id order = list order: the splat then walks the
@@ -780,6 +830,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     hipLaunchKernelGGL(renumber_points_kernel, dim3(1024), dim3(256), 0, s, rank, L.seg_start, n1k, n2k, L.cap, M, D + 1,
                        L.seg_lo, L.seg_hi, L.n1, L.n2);
     hipLaunchKernelGGL(renumber_entries_kernel, dim3(2048), dim3(256), 0, s, rank, ent_total, L.offset);
+    hipLaunchKernelGGL(nbr8_kernel, dim3(256, B), dim3(256), 0, s, L.n1, L.n2, L.cap, L.idbase, (D + 1) / 2, L.nbr8);
     // contributor segments into lattice-id order (scratch: keys_a = lengths, incl = new starts, keys_b = moved list)
     int* len = reinterpret_cast<int*>(keys_a);
     uint32_t* vals2 = reinterpret_cast<uint32_t*>(keys_b);
@@ -835,7 +886,7 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
     // mean-field 41.6 -> 37.0 ms per bench step, results bit-identical
     for (int j = 0; j <= D;) {
         if (j + 1 <= D) {
-            hipLaunchKernelGGL(crf_blur4x2_kernel, dim3(nb), dim3(256), 0, s, L, d_imgs, src, dst, j, img0, nimg);
+            hipLaunchKernelGGL(crf_blur4x2_kernel, dim3(nb), dim3(256), 0, s, L, d_imgs, src, dst, j / 2, img0, nimg);
             j += 2;
         } else {
             hipLaunchKernelGGL(crf_blur4_kernel, dim3(nb), dim3(256), 0, s, L, d_imgs, src, dst, j, img0, nimg);

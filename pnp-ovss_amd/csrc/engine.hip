@@ -1044,6 +1044,7 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
         KCHK(e, dalloc(e, &L.idbase, B + 1));
         KCHK(e, dalloc(e, &L.n1, cap * D1));
         KCHK(e, dalloc(e, &L.n2, cap * D1));
+        KCHK(e, dalloc(e, &L.nbr8, cap * (D1 / 2)));
         KCHK(e, dalloc(e, &p.seg_begin[t], B));
         KCHK(e, dalloc(e, &p.seg_end[t], B));
     }

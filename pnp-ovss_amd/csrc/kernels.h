@@ -31,6 +31,14 @@ struct alignas(16) CrfEntry {
     uint32_t pad;
 };
 
+// neighbour record of the two-axis lattice blur (crf_blur4x2_kernel): image-local lattice ids, -1 = absent
+struct alignas(16) CrfNbr8 {
+    int ia, id;        // neighbours along the pair's first axis
+    int pa, pd;        // neighbours along its second axis ...
+    int aa, ad;        // ... and their neighbours along the first axis
+    int da, dd;
+};
+
 // One permutohedral lattice type for a whole image batch (device pointers).
 struct CrfLattice {
     int D1;            // d + 1
@@ -47,6 +55,7 @@ struct CrfLattice {
     int* idbase;       // [B+1] first lattice id of each image
     int* n1;           // [(d+1) * cap]
     int* n2;
+    CrfNbr8* nbr8;     // [(d+1)/2 * cap] per axis pair
 };
 
 // vit_kernels.hip
