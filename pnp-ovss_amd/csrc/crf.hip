@@ -646,7 +646,8 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
                     s = __fadd_rn(s, e);
                 }
                 for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
-                for (int k = K; k < im.Kg; k++) row[k] = 0.f;
+                if (grp == im.G - 1)                                    // pad floats behind the last group stay zero
+                    for (int k = im.G * im.Kg; k < Kp; k++) tile[px * ldt + k] = 0.f;
             }
             __syncthreads();
             for (int item = tid; item < np * K4; item += 256) {

@@ -112,7 +112,7 @@ struct pnp_engine {
         int32_t* d_wt_off = nullptr;
         float *merged = nullptr, *thr = nullptr, *maps = nullptr, *maps2 = nullptr, *maps3 = nullptr, *stats = nullptr;
         float *unary = nullptr, *Q = nullptr, *va = nullptr, *vb = nullptr, *vga = nullptr, *vgb = nullptr, *norm[2] = {nullptr, nullptr};
-        int Kpmax = 0, maxH = 0, maxW = 0, max_radius = 0, maxKp = 0;
+        int Kpmax = 0, Kpmax_pair = 0, maxH = 0, maxW = 0, max_radius = 0, maxKp = 0;
         size_t valg_cap = 0;
         std::vector<int> gauss_sig;      // (H, W) list the Gaussian lattice was last built for
         const uint8_t* d_rgb = nullptr;
@@ -1101,7 +1101,7 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
         d.off = off;
         d.Kp = (d.K + 3) / 4 * 4;
         d.G = 1;
-        d.Kg = d.Kp;
+        d.Kg = d.K;
         d.qoff = qoff;
         label_off[i] = (size_t)pix;
         off += (size_t)d.K * d.H * d.W;
@@ -1138,12 +1138,17 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
     if (ncls > p.cls_cap || ntok > p.tok_cap) return fail(e, PNP_ERR_ARG, "merge plan exceeds reserved capacity");
     if (b->lut_stride < p.Kmax || B * b->lut_stride > p.lut_cap) return fail(e, PNP_ERR_ARG, "bad lut_stride");
     // lattice value offsets per chunk (upper bound: entries * K)
+    // the paired run (two channel groups per row, 1-drop | N-drop) packs the groups back to back: rows of
+    // 4 * ceil(2 K / 4) floats (K = 21: 44 instead of 2 x 24), its own row-strided offsets
+    std::vector<size_t> voff_pair(2 * (size_t)B, 0);
     for (int c0 = 0; c0 < B; c0 += p.chunk) {
-        size_t v[2] = {0, 0};
+        size_t v[2] = {0, 0}, v2[2] = {0, 0};
         for (int i = c0; i < std::min(B, c0 + p.chunk); i++)
             for (int t = 0; t < 2; t++) {
                 p.desc[i].voff[t] = v[t];
                 v[t] += (size_t)p.desc[i].H * p.desc[i].W * (t == 0 ? 3 : 6) * p.desc[i].Kp;
+                voff_pair[2 * (size_t)i + t] = v2[t];
+                v2[t] += (size_t)p.desc[i].H * p.desc[i].W * (t == 0 ? 3 : 6) * ((2 * p.desc[i].K + 3) / 4 * 4);
             }
         if (p.groups_cap * v[1] > p.val_cap || p.groups_cap * v[0] > p.valg_cap)     // incl. room for the paired run
             return fail(e, PNP_ERR_ARG, "CRF chunk needs %zu value floats, reserved %zu", p.groups_cap * v[1], p.val_cap);
@@ -1155,12 +1160,19 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
     p.d_gt = b->d_gt;
     HIPCHK(e, hipMemcpyAsync(p.d_desc, p.desc.data(), sizeof(PostDesc) * B, hipMemcpyHostToDevice, s));
     p.desc_pair = p.desc;
-    for (PostDesc& d : p.desc_pair) {          // rows of two groups: every row-strided offset doubles
-        d.G = 2;
-        d.Kp = 2 * d.Kg;
-        d.qoff *= 2;
-        d.voff[0] *= 2;
-        d.voff[1] *= 2;
+    p.Kpmax_pair = 0;
+    {
+        size_t qoff2 = 0;
+        for (int i = 0; i < B; i++) {          // rows of two groups
+            PostDesc& d = p.desc_pair[i];
+            d.G = 2;
+            d.Kp = (2 * d.K + 3) / 4 * 4;
+            d.qoff = qoff2;
+            qoff2 += (size_t)d.Kp * d.H * d.W;
+            d.voff[0] = voff_pair[2 * (size_t)i];
+            d.voff[1] = voff_pair[2 * (size_t)i + 1];
+            p.Kpmax_pair = std::max(p.Kpmax_pair, d.Kp);
+        }
     }
     HIPCHK(e, hipMemcpyAsync(p.d_desc_pair, p.desc_pair.data(), sizeof(PostDesc) * B, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(p.d_img_cls_off, b->img_cls_off, 4 * (B + 1), hipMemcpyHostToDevice, s));
@@ -1360,7 +1372,7 @@ extern "C" int pnp_postprocess_pair(pnp_engine* e, const float* d_gradcam_1drop,
         if (r) return r;
         KCHK(e, unary_from_maps(p.maps2, p.d_desc_pair, p.unary, p.B, p.maxHW, p.maxKp, grp, s));
     }
-    int r = crf_iterate(e, p.d_desc_pair, 2 * p.Kpmax, 10, 7.0f, 10.0f, s);
+    int r = crf_iterate(e, p.d_desc_pair, p.Kpmax_pair, 10, 7.0f, 10.0f, s);
     if (r) return r;
     for (int grp = 0; grp < 2; grp++) {
         uint8_t* lab = grp == 0 ? d_labels_1drop : d_labels_ndrop;

@@ -14,9 +14,9 @@ namespace pnp {
 // lattice value block (t = 0 Gaussian, 1 bilateral).
 struct PostDesc {
     int H, W, K, C, has_bg, pix0;
-    int Kp;            // row stride of the CRF arrays in floats: G groups of Kg
+    int Kp;            // row stride of the CRF arrays in floats: G groups of Kg back to back, zero-padded to a multiple of 4
     int G, Kg;         // channel groups per row (1; 2 = the 1-drop and N-drop problems of one batch side by side, which
-                       // share every lattice index walk) and floats per group (K rounded up to a multiple of 4)
+                       // share every lattice index walk) and floats per group (= K)
     size_t off;        // K*H*W blocks of the (K,H,W) map buffers
     size_t qoff;       // Kp*H*W blocks of the pixel-major CRF arrays (unary, Q)
     size_t voff[2];

@@ -490,12 +490,18 @@ int preprocess_images(const uint8_t* rgb, const void* desc, int B, int S, int ma
 // (densecrf's value layout).  include/pnp_math.h defines exp/log bit-exactly for host and device.
 __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc,
                                                     float* __restrict__ unary, int group) {
-    // tile of 256 pixels: channel-major reads (coalesced along pixels), results parked in LDS [pixel][Kp + 1], then
-    // written as whole 16-byte chunks of the pixel-major rows (the per-thread row writes were 4 bytes at a 96-byte stride)
+    // tile of 256 pixels: channel-major reads (coalesced along pixels), results parked in LDS [pixel][K + 1], then
+    // written as whole 16-byte chunks of the pixel-major rows (the per-thread row writes were 4 bytes at a 96-byte stride).
+    // A row holds G groups of K floats back to back (+ zero pad to a multiple of 4): this call owns floats [f0, f1) of
+    // every row.  A chunk it shares with the previous group (f0 not a multiple of 4) is read back and completed -- the
+    // groups of a row are written by successive launches on one stream; floats behind f1 are written as zeros (the next
+    // group's launch, or nobody: the pad).
     extern __shared__ __attribute__((aligned(16))) float utile[];
     const int b = blockIdx.y;
     const PostDesc d = desc[b];
-    const int n = d.H * d.W, K = d.K, Kp = d.Kg, K4 = Kp >> 2, ldt = Kp + 1, R4 = d.Kp >> 2, g4 = group * K4;   // row = G groups of Kg
+    const int n = d.H * d.W, K = d.K, ldt = K + 1, R4 = d.Kp >> 2;
+    const int f0 = group * d.Kg, f1 = f0 + K;
+    const int c_lo = f0 >> 2, c_hi = group == d.G - 1 ? R4 : (f1 + 3) >> 2, nc = c_hi - c_lo;
     const float* m = maps + d.off;
     f32x4* u4 = reinterpret_cast<f32x4*>(unary + d.qoff);
     const int tid = threadIdx.x;
@@ -517,13 +523,20 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ ma
                 else if (p > 1.0f) p = 1.0f;
                 row[k] = -pnp_logf(p);
             }
-            for (int k = K; k < Kp; k++) row[k] = 0.f;
         }
         __syncthreads();
-        for (int item = tid; item < np * K4; item += 256) {
-            const int pl = item / K4, c = item - pl * K4;
-            const float* r = utile + pl * ldt + 4 * c;
-            u4[(size_t)(p0 + pl) * R4 + g4 + c] = f32x4{r[0], r[1], r[2], r[3]};
+        for (int item = tid; item < np * nc; item += 256) {
+            const int pl = item / nc, c = c_lo + (item - pl * nc);
+            const float* r = utile + pl * ldt;
+            f32x4* dst = u4 + (size_t)(p0 + pl) * R4 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (4 * c < f0) v = *dst;                                    // the previous group's floats of a shared chunk
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int f = 4 * c + j;
+                if (f >= f0) v[j] = f < f1 ? r[f - f0] : 0.f;
+            }
+            *dst = v;
         }
         __syncthreads();
     }
@@ -541,13 +554,14 @@ __global__ void argmax_kernel(const float* __restrict__ q, const PostDesc* __res
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int best = 0;
         float bv = pixel_major ? p[(size_t)i * Kp + group * d.Kg] : p[i];
-        if (pixel_major) {                          // rows are G groups of Kg = 4 * ceil(K / 4) floats, 16-byte aligned
-            const f32x4* row = reinterpret_cast<const f32x4*>(p + (size_t)i * Kp + group * d.Kg);
-            for (int c = 0; c < d.Kg / 4; c++) {
+        if (pixel_major) {                          // rows are G groups of Kg = K floats back to back: aligned 16-byte chunks
+            const int f0 = group * d.Kg;            // covering floats [f0, f0 + K)
+            const f32x4* row = reinterpret_cast<const f32x4*>(p + (size_t)i * Kp);
+            for (int c = f0 >> 2; c < (f0 + K + 3) >> 2; c++) {
                 const f32x4 v4 = row[c];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const int k = c * 4 + j;
+                    const int k = c * 4 + j - f0;
                     const float v = v4[j];
                     if (k >= 1 && k < K && bv == bv && (v > bv || v != v)) { best = k; bv = v; }
                 }
