@@ -571,8 +571,8 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
                                                          const float* __restrict__ norm_g, const float* __restrict__ norm_b,
                                                          const float* __restrict__ unary, float* __restrict__ Q, float w_g,
                                                          float w_b, float alpha_g, float alpha_b, int pairwise, int img0,
-                                                         int nimg) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];        // [CRF_TP][Kp + 1]
+                                                         int nimg, int tp_cap) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];        // [TP][Kp + 1], then the slice records [TP][20]
     // XCD-affine sweep like the splat / blur kernels: the slice gathers of an image hit the value rows
     // its XCD has just blurred
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, bpx = gridDim.x >> 3;
@@ -583,52 +583,91 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
         const int npix = im.H * im.W;
         const int pfirst = (int)((long)npix * part / parts), n = (int)((long)npix * (part + 1) / parts);
         const int K = im.K, Kp = im.Kp, K4 = Kp >> 2, ldt = Kp + 1;
-        const f32x4* U4 = reinterpret_cast<const f32x4*>(unary + im.qoff);
         f32x4* Q4 = reinterpret_cast<f32x4*>(Q + im.qoff);
         const int lo_g = pairwise ? Lg.idbase[b] : 0, lo_b = pairwise ? Lb.idbase[b] : 0;
-        const f32x4* G4 = reinterpret_cast<const f32x4*>(vg + im.voff[0]);
-        const f32x4* B4 = reinterpret_cast<const f32x4*>(vb + im.voff[1]);
-        const int TP = CRF_TP / im.G;                                   // pixels per tile: one softmax thread per (pixel, group)
+        const int TP = CRF_TP / im.G < tp_cap ? CRF_TP / im.G : tp_cap; // pixels per tile: one softmax thread per (pixel, group)
+        // rows of the pixel-major arrays and of the lattice value arrays as base + 32-bit byte offset
+        const char* const Ub = reinterpret_cast<const char*>(unary + im.qoff);
+        const char* const Gb = reinterpret_cast<const char*>(vg + im.voff[0]);
+        const char* const Bb = reinterpret_cast<const char*>(vb + im.voff[1]);
+        const uint32_t rowb = (uint32_t)K4 * 16u;
+        int* const rec_ob = reinterpret_cast<int*>(tile + TP * ldt);                   // [TP][6] bilateral ids, then ...
+        float* const rec_wb = reinterpret_cast<float*>(rec_ob + TP * 6);
+        int* const rec_og = reinterpret_cast<int*>(rec_wb + TP * 6);
+        float* const rec_wg = reinterpret_cast<float*>(rec_og + TP * 3);
+        float* const rec_nb = rec_wg + TP * 3;
+        float* const rec_ng = rec_nb + TP;
+        const int q256 = 256 / K4, r256 = 256 - q256 * K4;             // item -> (pixel, chunk) advance without a division
+        const int pl0 = tid / K4, c0 = tid - pl0 * K4;
         for (int p0 = pfirst + slot * TP; p0 < n; p0 += bpx * TP) {
             const int np = (n - p0) < TP ? (n - p0) : TP;
-            for (int item = tid; item < np * K4; item += 256) {
-                const int pl = item / K4, c = item - pl * K4;
-                const int pix = p0 + pl;
-                const f32x4 u = U4[(size_t)pix * K4 + c];
-                f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
-                if (pairwise) {
-                    const size_t gp = (size_t)im.pix0 + pix;
-                    {
-                        f32x4 out = {0.f, 0.f, 0.f, 0.f};
-                        const size_t pv0 = gp * 3;
+            // the tile's per-pixel slice records -- 6 + 3 image-local lattice ids and barycentric weights, two normalisers --
+            // are staged once through LDS (coalesced loads) instead of being fetched by every channel-chunk lane of the
+            // pixel: 10 vector-memory instructions per (pixel, chunk) item instead of 30 (the kernel is issue-bound there)
+            if (pairwise) {
+                const size_t gp0 = (size_t)im.pix0 + p0;
+                for (int i = tid; i < np * 6; i += 256) {
+                    rec_ob[i] = Lb.offset[gp0 * 6 + i] - lo_b;
+                    rec_wb[i] = Lb.bary[gp0 * 6 + i];
+                }
+                for (int i = tid; i < np * 3; i += 256) {
+                    rec_og[i] = Lg.offset[gp0 * 3 + i] - lo_g;
+                    rec_wg[i] = Lg.bary[gp0 * 3 + i];
+                }
+                for (int i = tid; i < np; i += 256) {
+                    rec_nb[i] = norm_b[gp0 + i];
+                    rec_ng[i] = norm_g[gp0 + i];
+                }
+                __syncthreads();
+            }
+            {
+                int pl = pl0, c = c0;
+                for (int item = tid; item < np * K4; item += 256) {
+                    const uint32_t cofs = (uint32_t)c * 16u;
+                    const f32x4 u = *reinterpret_cast<const f32x4*>(Ub + (__umul24((uint32_t)(p0 + pl), rowb) + cofs));
+                    f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
+                    if (pairwise) {
+                        f32x4 vg3[3], vb6[6];
 #pragma unroll
-                        for (int v = 0; v < 3; v++) {
-                            const f32x4 val = G4[(size_t)(Lg.offset[pv0 + v] - lo_g) * K4 + c];
-                            const float wv = Lg.bary[pv0 + v];
+                        for (int v = 0; v < 3; v++)
+                            vg3[v] = *reinterpret_cast<const f32x4*>(Gb + (__umul24((uint32_t)rec_og[pl * 3 + v], rowb) + cofs));
 #pragma unroll
-                            for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_g));
+                        for (int v = 0; v < 6; v++)
+                            vb6[v] = *reinterpret_cast<const f32x4*>(Bb + (__umul24((uint32_t)rec_ob[pl * 6 + v], rowb) + cofs));
+                        {
+                            f32x4 out = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int v = 0; v < 3; v++) {
+                                const float wv = rec_wg[pl * 3 + v];
+#pragma unroll
+                                for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, vg3[v][i]), alpha_g));
+                            }
+                            const float nr = rec_ng[pl];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_g, __fmul_rn(out[i], nr)));
                         }
-                        const float nr = norm_g[gp];
+                        {
+                            f32x4 out = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_g, __fmul_rn(out[i], nr)));
+                            for (int v = 0; v < 6; v++) {
+                                const float wv = rec_wb[pl * 6 + v];
+#pragma unroll
+                                for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, vb6[v][i]), alpha_b));
+                            }
+                            const float nr = rec_nb[pl];
+#pragma unroll
+                            for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_b, __fmul_rn(out[i], nr)));
+                        }
                     }
-                    {
-                        f32x4 out = {0.f, 0.f, 0.f, 0.f};
-                        const size_t pv0 = gp * 6;
 #pragma unroll
-                        for (int v = 0; v < 6; v++) {
-                            const f32x4 val = B4[(size_t)(Lb.offset[pv0 + v] - lo_b) * K4 + c];
-                            const float wv = Lb.bary[pv0 + v];
-#pragma unroll
-                            for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, val[i]), alpha_b));
-                        }
-                        const float nr = norm_b[gp];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_b, __fmul_rn(out[i], nr)));
+                    for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
+                    pl += q256;
+                    c += r256;
+                    if (c >= K4) {
+                        c -= K4;
+                        pl++;
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
             }
             __syncthreads();
             if (tid < np * im.G) {                                      // one softmax per (pixel, channel group)
@@ -905,7 +944,12 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
 int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
                const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
                float w_b, int pairwise, int max_pixels, int max_kp, int groups, hipStream_t s) {
-    const size_t smem = (size_t)(CRF_TP / (groups > 0 ? groups : 1)) * (max_kp + 1) * sizeof(float);
+    // tile + per-pixel slice records; wide rows (150 classes) take fewer pixels per tile to stay inside the CU's 160 KB
+    size_t tp = (size_t)(CRF_TP / (groups > 0 ? groups : 1));
+    const size_t per_pixel = ((size_t)max_kp + 1 + 20) * sizeof(float);
+    if (tp * per_pixel > 160 * 1024) tp = 160 * 1024 / per_pixel;
+    if (tp < 1) return PNP_ERR_ARG;
+    const size_t smem = tp * per_pixel;
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(crf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)smem) != hipSuccess)
@@ -913,7 +957,7 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
     }
     (void)max_pixels;
     hipLaunchKernelGGL(crf_update_kernel, dim3(8 * 256), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
-                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg);
+                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp);
     return ok();
 }
 
