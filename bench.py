@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=35, help="images per step per GPU (--batch_size 35, Run_seg.sh)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"],
@@ -498,6 +498,15 @@ def run_rank(a):
                 rec = {"dtype": pm, "value": B * a.parity_steps / dt3, "unit": "images/sec",
                        "ms_per_step": 1e3 * dt3 / a.parity_steps, "steps": a.parity_steps, "warmup": 1, "batches_in_flight": 1,
                        "roofline": roofline_gemm(pm, gemm3), "crf_ms_per_step": crf3[2] / a.parity_steps}
+                if pm == "bf16x3" and P > 1:
+                    # the parity mode with the headline's batches in flight (per-kernel records: the pass above)
+                    more = [make_engine(pm) for _ in range(P - 1)]
+                    nst = max(a.parity_steps, P)
+                    dt3p, _ = timed_run_pipelined([e] + more, a.noise, nst, 1)
+                    for ex in more:
+                        ex.close()
+                    rec.update({"value": B * nst / dt3p, "ms_per_step": 1e3 * dt3p / nst, "steps": nst, "batches_in_flight": P,
+                                "one_batch_at_a_time": {"value": B * a.parity_steps / dt3, "ms_per_step": 1e3 * dt3 / a.parity_steps}})
                 if pm == "bf16x3":
                     out["parity_mode"] = rec
                 else:
