@@ -602,6 +602,72 @@ def test_postprocess_nan_channel_semantics():
         np.testing.assert_array_equal(labels[b].cpu().numpy().astype(np.float32), OP.remap_labels(lab, best[b], True))
 
 
+def test_engines_in_flight_match_one_at_a_time():
+    """bench.py --pipelines / the CLI keep several batches in flight per GPU: distinct engines, each driven from its own host
+    thread on its own HIP stream (include/pnp_hip.h: distinct handles are independent).  Three engines running the whole
+    path concurrently -- drop loop, lattice build, paired blur + CRF, histogram -- must reproduce, bit for bit, what one of
+    them produces alone (different seeds per engine input so that a cross-talk between workspaces would show)."""
+    import threading
+    from pnp_ovss.hip import Engine
+    g = _golden("droploop_small.npz")
+    cfg = _cfg(g)
+    _ENG.clear()
+    P, B, K = 3, 3, 5
+    sd = synth.synth_state_dict(cfg, int(g["weight_seed"]))
+    ids, mask = _dev(g["input_ids"]), _dev(g["attention_mask"])
+    L = int(g["attention_mask"].sum(1).max())
+    S = cfg.img_size
+    engines, inputs = [], []
+    for p in range(P):
+        e = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, mode="f32")
+        e.load_state_dict(sd)
+        e.post_reserve(B, B * S * S, S * S, K + 1, 0)
+        engines.append(e)
+        rgb, imgs = synth.synth_images(B, S, seed=100 + p)
+        gt = np.random.default_rng(p).integers(0, K + 1, size=(B, S, S)).astype(np.float32)
+        inputs.append((_dev(imgs), _dev(rgb.reshape(-1)), _dev(gt.reshape(-1))))
+    plans = [[([i], 1) for i in range(K)]] * B
+    luts = [list(range(K + 1))] * B
+
+    def whole_path(p, reps):
+        e = engines[p]
+        d_img, d_rgb, d_gt = inputs[p]
+        out = None
+        for _ in range(reps):
+            h1 = torch.zeros((K + 1) ** 2, device="cuda", dtype=torch.int64)
+            hn = torch.zeros((K + 1) ** 2, device="cuda", dtype=torch.int64)
+            g0, agg, picks, _ = e.drop_loop(d_img, ids, mask, L, 9, 4)
+            e.post_prepare([(S, S)] * B, plans, luts, [True] * B, rgb=d_rgb, gt=d_gt, want_crf=True)
+            l1, ln = e.postprocess_pair(g0, agg, 0.15, K + 1, h1, hn)
+            out = (picks, g0, agg, l1, ln, h1, hn)
+        torch.cuda.current_stream().synchronize()
+        return [t.cpu().numpy() for t in out]
+
+    alone = [whole_path(p, 1) for p in range(P)]
+    together, errors = [None] * P, []
+
+    def worker(p):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                together[p] = whole_path(p, 4)
+        except Exception as ex:          # noqa: BLE001
+            errors.append(repr(ex))
+
+    ths = [threading.Thread(target=worker, args=(p,)) for p in range(P)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for p in range(P):
+        for a, b in zip(alone[p], together[p]):
+            np.testing.assert_array_equal(a, b)
+    assert any((alone[0][3] != alone[1][3]).ravel())          # the engines really worked on different images
+    for e in engines:
+        e.close()
+
+
 def test_full_size_properties_336():
     """Size-independent properties at the benchmark geometry (336^2, K = 21, blur + CRF)."""
     cfg = C.blip_itm_large(336)
