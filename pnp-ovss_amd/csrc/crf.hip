@@ -12,6 +12,8 @@
 // (blockIdx.y = image).  HBM-bound: values are streamed, nothing is reshaped into a GEMM.
 #include <hipcub/hipcub.hpp>
 
+#include <mutex>
+
 #include "common.h"
 #include "kernels.h"
 #include "../../include/pnp_math.h"
@@ -884,6 +886,21 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
 
 static float crf_alpha(int D) { return 1.0f / (1 + powf(2, (float)-D)); }
 
+// Grid of the XCD-affine iteration kernels: 8 XCD groups x the workgroups that are RESIDENT per XCD for this kernel
+// (occupancy query x CUs per XCD).  Each workgroup walks its share of every image of its XCD, so a grid larger than what is
+// resident runs as a second wave of workgroups after the first has swept all its images: unbalanced, and the second wave
+// re-fetches from HBM every Q / value row the first one had in L2.
+template <typename F>
+static int resident_grid(F kernel, int threads, size_t smem) {
+    int dev = 0, cus = 256, occ = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, smem) != hipSuccess || occ < 1) occ = 1;
+    const int per_xcd = (cus / 8 > 0 ? cus / 8 : 1) * occ;
+    return 8 * (per_xcd < 256 ? per_xcd : 256);
+}
+
 // norm = 1 / sqrt(lattice(ones) + 1e-20) for images [0,B); va/vb: scratch of >= (number of lattice points) floats.
 int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, size_t ent_total, float* va, float* vb,
                      float* norm_out, hipStream_t s) {
@@ -908,28 +925,30 @@ int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
                float* va, float* vb, const float** result, int max_kp, hipStream_t s) {
     const int D = L.D1 - 1;
-    const int nb = 8 * 256;                                 // 8 XCD groups x 256 resident workgroups per XCD
     const int k4 = (max_kp + 3) / 4;
 #define PNP_SPLAT(LPP_, MULTI_)                                                                                                  \
     do {                                                                                                                      \
-        if (L.which == 0) hipLaunchKernelGGL((crf_splat_kernel<LPP_, 0, MULTI_>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg); \
-        else hipLaunchKernelGGL((crf_splat_kernel<LPP_, 1, MULTI_>), dim3(nb), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg);              \
+        static const int nbs0 = resident_grid(crf_splat_kernel<LPP_, 0, MULTI_>, 256, 0);                                     \
+        static const int nbs1 = resident_grid(crf_splat_kernel<LPP_, 1, MULTI_>, 256, 0);                                     \
+        if (L.which == 0) hipLaunchKernelGGL((crf_splat_kernel<LPP_, 0, MULTI_>), dim3(nbs0), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg); \
+        else hipLaunchKernelGGL((crf_splat_kernel<LPP_, 1, MULTI_>), dim3(nbs1), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg);              \
     } while (0)
     if (k4 <= 8) PNP_SPLAT(8, false);
     else if (k4 <= 16) PNP_SPLAT(16, false);
     else if (k4 <= 32) PNP_SPLAT(32, false);
     else PNP_SPLAT(32, true);
 #undef PNP_SPLAT
+    static const int nb2 = resident_grid(crf_blur4x2_kernel, 256, 0), nb1 = resident_grid(crf_blur4_kernel, 256, 0);
     float* src = va;
     float* dst = vb;
     // axes in pairs through the fused two-axis kernel (bilateral: 3 passes for 6 axes; Gaussian: one pair + one single):
     // mean-field 41.6 -> 37.0 ms per bench step, results bit-identical
     for (int j = 0; j <= D;) {
         if (j + 1 <= D) {
-            hipLaunchKernelGGL(crf_blur4x2_kernel, dim3(nb), dim3(256), 0, s, L, d_imgs, src, dst, j / 2, img0, nimg);
+            hipLaunchKernelGGL(crf_blur4x2_kernel, dim3(nb2), dim3(256), 0, s, L, d_imgs, src, dst, j / 2, img0, nimg);
             j += 2;
         } else {
-            hipLaunchKernelGGL(crf_blur4_kernel, dim3(nb), dim3(256), 0, s, L, d_imgs, src, dst, j, img0, nimg);
+            hipLaunchKernelGGL(crf_blur4_kernel, dim3(nb1), dim3(256), 0, s, L, d_imgs, src, dst, j, img0, nimg);
             j += 1;
         }
         float* t = src;
@@ -956,7 +975,24 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
             return PNP_ERR_HIP;
     }
     (void)max_pixels;
-    hipLaunchKernelGGL(crf_update_kernel, dim3(8 * 256), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
+    // (the occupancy depends on the tile's LDS bytes: queried per distinct size, a handful per process)
+    static size_t grid_smem[8];
+    static int grid_nb[8], grid_n = 0;
+    static std::mutex grid_mu;                               // engines of different host threads share the table
+    int nbu = 0;
+    {
+        std::lock_guard<std::mutex> lk(grid_mu);
+        for (int i = 0; i < grid_n; i++)
+            if (grid_smem[i] == smem) nbu = grid_nb[i];
+        if (!nbu) {
+            nbu = resident_grid(crf_update_kernel, 256, smem);
+            if (grid_n < 8) {
+                grid_smem[grid_n] = smem;
+                grid_nb[grid_n++] = nbu;
+            }
+        }
+    }
+    hipLaunchKernelGGL(crf_update_kernel, dim3(nbu), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
                        w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp);
     return ok();
 }
