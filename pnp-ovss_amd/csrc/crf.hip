@@ -796,13 +796,23 @@ __global__ void seg_len_kernel(const int* __restrict__ seg_lo, const int* __rest
 __global__ void move_segments_kernel(const uint32_t* __restrict__ vals, const int* __restrict__ new_start, int M, int D1,
                                      const float* __restrict__ bary, int* __restrict__ seg_lo, int* __restrict__ seg_hi,
                                      uint32_t* __restrict__ vals2, CrfEntry* __restrict__ ent) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+    // eight lanes per lattice point: the entries of a segment are copied side by side (one thread per point walked its
+    // segment alone: 16-byte records at scattered addresses, 0.49 ms per build)
+    const long nthr = (long)gridDim.x * blockDim.x;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < (long)M * 8; t += nthr) {
+        const int i = (int)(t >> 3), j0 = (int)(t & 7);
         const int a = seg_lo[i], n = seg_hi[i] - a, d = new_start[i];
-        for (int j = 0; j < n; j++) {
+        for (int j = j0; j < n; j += 8) {
             const uint32_t pv = vals[a + j];
             vals2[d + j] = pv;
             ent[d + j] = CrfEntry{pv / (uint32_t)D1, bary[pv], 0.f, 0u};  // the splat's contributor record (nr: crf_lattice_norm)
         }
+    }
+}
+// (the segment bounds are rewritten once every lane group has read the old ones: separate launch)
+__global__ void set_segments_kernel(const int* __restrict__ new_start, int M, int* __restrict__ seg_lo, int* __restrict__ seg_hi) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const int n = seg_hi[i] - seg_lo[i], d = new_start[i];
         seg_lo[i] = d;
         seg_hi[i] = d + n;
     }
@@ -879,7 +889,8 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     hipLaunchKernelGGL(seg_len_kernel, dim3(1024), dim3(256), 0, s, L.seg_lo, L.seg_hi, M, len);
     tb = temp_bytes;
     if (hipcub::DeviceScan::ExclusiveSum(temp, tb, len, incl, M, s) != hipSuccess) return PNP_ERR_HIP;
-    hipLaunchKernelGGL(move_segments_kernel, dim3(2048), dim3(256), 0, s, L.vals, incl, M, D + 1, L.bary, L.seg_lo, L.seg_hi, vals2, L.ent);
+    hipLaunchKernelGGL(move_segments_kernel, dim3(4096), dim3(256), 0, s, L.vals, incl, M, D + 1, L.bary, L.seg_lo, L.seg_hi, vals2, L.ent);
+    hipLaunchKernelGGL(set_segments_kernel, dim3(1024), dim3(256), 0, s, incl, M, L.seg_lo, L.seg_hi);
     if (hipMemcpyAsync(L.vals, vals2, ent_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return PNP_ERR_HIP;
     return ok();
 }
