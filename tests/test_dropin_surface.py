@@ -63,6 +63,31 @@ def test_cli_synthetic_end_to_end(tmp_path):
     assert r.returncode == 0 and "Mean IoU" in r.stdout
 
 
+def test_cli_pipelines_write_the_same_files(tmp_path):
+    """--pipelines 2 (two model replicas taking the batches on their own streams / host threads) must leave exactly the
+    files a one-replica run leaves: same names, same confusion matrices."""
+    outs = []
+    for P in (1, 2):
+        save = tmp_path / f"out{P}"
+        cmd = [sys.executable, os.path.join(ROOT, "pnp-ovss_amd", "PnP_OVSS_0514_updated_segmentation.py"),
+               "--save_path", str(save), "--world_size", "1", "--img_size", "336", "--del_patch_num", "sort_thresh005",
+               "--batch_size", "2", "--max_att_block_num", "8", "--drop_iter", "2", "--prune_att_head", "9",
+               "--sort_threshold", "0.05", "--threshold", "0.15", "--postprocess", "blur+crf", "--data_type", "synthetic",
+               "--synthetic_images", "8", "--pipelines", str(P)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        files = {}
+        for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
+            for f in sorted(glob.glob(str(save / d / "*.npy"))):
+                files[d + "/" + os.path.basename(f)] = np.load(f)
+        outs.append((files, json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])))
+    (f1, s1), (f2, s2) = outs
+    assert len(f1) == 8 and sorted(f1) == sorted(f2)
+    for k in f1:
+        np.testing.assert_array_equal(f1[k], f2[k])
+    assert s1["images"] == s2["images"] == 8 and s1["Mean IoU"] == s2["Mean IoU"]
+
+
 def test_voc_dataset_device_preprocess_equals_host_pillow_path(tmp_path):
     """`--data_type voc` input side on a tiny fake VOCdevkit: the batch tensor produced by the device resize +
     normalise equals the reference's host recipe (PIL bicubic resize -> /255 -> (x - mean) / std, Dataset.py:434-443)

@@ -2,7 +2,7 @@
 table on disk -> `PnP_OVSS_0514_updated_segmentation.py --data_type voc` -> histograms on disk, i.e. everything a user of the
 reference's Run_seg.sh runs, next to `bench.py`'s device-resident number.
 
-    python tools/cli_e2e.py [--images 350] [--batch 35] [--dtype bf16] [--profile] [--device_jpeg 1]
+    python tools/cli_e2e.py [--images 350] [--batch 35] [--dtype bf16] [--profile] [--device_jpeg 1] [--pipelines 1]
 
 --profile runs the loop under cProfile and prints the host functions by cumulative time.
 """
@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--device_jpeg", type=int, default=1)
     ap.add_argument("--profile", action="store_true")
+    ap.add_argument("--pipelines", type=int, default=1)
     a = ap.parse_args()
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
         home = Path(tmp)
@@ -71,7 +72,7 @@ def main():
         argv = ["--batch_size", str(a.batch), "--home_dir", str(home), "--save_path", str(home / "out"), "--img_size", "336",
                 "--del_patch_num", "sort_thresh005", "--max_att_block_num", "8", "--drop_iter", "4", "--prune_att_head", "9",
                 "--sort_threshold", "0.05", "--threshold", "0.15", "--postprocess", "blur+crf", "--data_type", "voc",
-                "--world_size", "1", "--dtype", a.dtype, "--device_jpeg", str(a.device_jpeg)]
+                "--world_size", "1", "--dtype", a.dtype, "--device_jpeg", str(a.device_jpeg), "--pipelines", str(a.pipelines)]
         args = cli.get_args_parser().parse_args(argv)
         buf = io.StringIO()
         real = sys.stdout
