@@ -833,9 +833,9 @@ size_t crf_sort_temp_bytes(size_t max_entries, int max_images) {
 // Build one lattice (D = 2: Gaussian xy/sxy ; D = 5: bilateral xy/sxy, rgb/srgb) for images [0,B).
 // Scratch arrays (keys/vals double buffers, head, incl, temp) are caller-provided.
 int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
-                      int B, size_t ent_total, int max_pixels, const int* d_seg_begin, const int* d_seg_end,
+                      int B, size_t ent_total, int max_pixels,
                       uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
-                      void* temp, size_t temp_bytes, int* d_range_err, hipStream_t s) {
+                      void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, hipStream_t s) {
     const int nb = (max_pixels + 255) / 256 < 512 ? (max_pixels + 255) / 256 : 512;
     if (D == 2)
         hipLaunchKernelGGL((lattice_embed_kernel<2>), dim3(nb, B), dim3(256), 0, s, d_imgs, d_rgb, sxy, srgb, L.bary, keys_a, vals_a, d_range_err);
@@ -844,8 +844,6 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     else
         return PNP_ERR_ARG;
     if (B > (1 << IMG_BITS)) return PNP_ERR_ARG;
-    (void)d_seg_begin;
-    (void)d_seg_end;
     // bits actually populated: coordinates (D * BITS, low) + image index (IMG_SHIFT..)
     int img_bits = 0;
     while ((1 << img_bits) < B) img_bits++;
@@ -865,8 +863,12 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
         hipLaunchKernelGGL((neighbors_kernel<5>), dim3(nbe, B), dim3(256), 0, s, L.ukeys, L.idbase, L.cap, n1k, n2k);
     // spatial renumbering (needs the lattice size on the host: one small read-back per build)
     int M = 0;
+    // (the key-range flag of the embed kernel rides on the same synchronisation)
+    int err = 0;
     if (hipMemcpyAsync(&M, L.idbase + B, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return PNP_ERR_HIP;
+    if (hipMemcpyAsync(&err, d_range_err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return PNP_ERR_HIP;
     if (hipStreamSynchronize(s) != hipSuccess) return PNP_ERR_HIP;
+    if (err && h_range_err) *h_range_err = 1;
     if (M <= 0 || (size_t)M > ent_total) return PNP_ERR_STATE;
     uint64_t* fkey = keys_a;
     uint64_t* skey = keys_b;

@@ -121,7 +121,11 @@ struct pnp_engine {
         uint64_t *keys_a = nullptr, *keys_b = nullptr;
         uint32_t* vals_a = nullptr;
         int *n1k = nullptr, *n2k = nullptr;
-        int *head = nullptr, *incl = nullptr, *seg_begin[2] = {nullptr, nullptr}, *seg_end[2] = {nullptr, nullptr}, *range_err = nullptr;
+        int *head = nullptr, *incl = nullptr, *range_err = nullptr;
+        int range_err_host = 0;                // key-range flag of the lattices built by the last prepare
+        std::vector<size_t> h_label_off;       // host staging of the per-batch tables (see pnp_post_prepare)
+        std::vector<int32_t> h_wt_off;
+        std::vector<double> h_wts;
         void* sort_tmp = nullptr;
         size_t sort_tmp_bytes = 0;
         size_t cap[2] = {0, 0};
@@ -1045,8 +1049,6 @@ extern "C" int pnp_post_reserve(pnp_engine* e, int32_t max_batch, int64_t max_to
         KCHK(e, dalloc(e, &L.n1, cap * D1));
         KCHK(e, dalloc(e, &L.n2, cap * D1));
         KCHK(e, dalloc(e, &L.nbr8, cap * (D1 / 2)));
-        KCHK(e, dalloc(e, &p.seg_begin[t], B));
-        KCHK(e, dalloc(e, &p.seg_end[t], B));
     }
     const size_t cap6 = p.cap[1];
     KCHK(e, dalloc(e, &p.keys_a, cap6));
@@ -1085,9 +1087,14 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
     const int B = b->B;
     p.prepared = false;
     p.desc.assign(B, PostDesc{});
-    std::vector<size_t> label_off(B + 1, 0);
-    std::vector<int32_t> wt_off(B + 1, 0);
-    std::vector<double> wts;
+    // host staging of the small tables lives in the engine until the next prepare (pageable memory: the runtime copies it
+    // into its own staging buffer at enqueue time, so rewriting it on the next call is safe without a synchronisation)
+    std::vector<size_t>& label_off = p.h_label_off;
+    std::vector<int32_t>& wt_off = p.h_wt_off;
+    std::vector<double>& wts = p.h_wts;
+    label_off.assign(B + 1, 0);
+    wt_off.assign(B + 1, 0);
+    wts.clear();
     size_t off = 0, qoff = 0;
     int64_t pix = 0;
     p.Cmax = p.Kmax = p.maxHW = p.Kpmax = p.maxH = p.maxW = p.max_radius = 0;
@@ -1183,8 +1190,10 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
     HIPCHK(e, hipMemcpyAsync(p.d_label_off, label_off.data(), sizeof(size_t) * (B + 1), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(p.d_wts, wts.data(), 8 * wts.size(), hipMemcpyHostToDevice, s));
     HIPCHK(e, hipMemcpyAsync(p.d_wt_off, wt_off.data(), 4 * (B + 1), hipMemcpyHostToDevice, s));
-    HIPCHK(e, hipStreamSynchronize(s));      // host vectors above go out of scope
     p.has_crf = false;
+    // the table copies above read caller / engine host memory asynchronously: they are complete behind the lattice build's own
+    // read-back (one synchronisation per batch, inside crf_build_lattice); without a lattice to build, wait here
+    bool synced = false;
     if (want_crf) {
         // PnP.py:1036-1041: POS_XY_STD = 3, Bi_XY_STD = 50, Bi_RGB_STD = 5 (features are fixed per batch)
         std::vector<int> sig;
@@ -1193,23 +1202,14 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
             // the Gaussian (xy-only) lattice depends on the image sizes alone: keep it across batches
             if (t == 0 && sig == p.gauss_sig) continue;
             const int D1 = t == 0 ? 3 : 6;
-            std::vector<int> sb(B), se(B);
-            for (int i = 0; i < B; i++) {
-                sb[i] = p.desc[i].pix0 * D1;
-                se[i] = sb[i] + p.desc[i].H * p.desc[i].W * D1;
-            }
-            HIPCHK(e, hipMemcpyAsync(p.seg_begin[t], sb.data(), 4 * B, hipMemcpyHostToDevice, s));
-            HIPCHK(e, hipMemcpyAsync(p.seg_end[t], se.data(), 4 * B, hipMemcpyHostToDevice, s));
-            HIPCHK(e, hipStreamSynchronize(s));
             KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
-                                      p.maxHW, p.seg_begin[t], p.seg_end[t], p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
-                                      p.n1k, p.n2k, p.sort_tmp, p.sort_tmp_bytes, p.range_err, s));
+                                      p.maxHW, p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
+                                      p.n1k, p.n2k, p.sort_tmp, p.sort_tmp_bytes, p.range_err, &p.range_err_host, s));
             KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.maxHW, (size_t)pix * D1, p.va, p.vb, p.norm[t], s));
+            synced = true;
         }
-        int err = 0;
-        HIPCHK(e, hipMemcpyAsync(&err, p.range_err, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(e, hipStreamSynchronize(s));
-        if (err) {                           // leave no stale state behind: the next prepare rebuilds both lattices
+        if (p.range_err_host) {                // (read back with the lattice size inside crf_build_lattice: no extra sync)
+            p.range_err_host = 0;                           // leave no stale state behind: the next prepare rebuilds both lattices
             p.gauss_sig.clear();
             (void)hipMemsetAsync(p.range_err, 0, 4, s);
             return fail(e, PNP_ERR_ARG, "lattice key out of packing range (image too large for the 64-bit key)");
@@ -1217,6 +1217,7 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
         p.gauss_sig = sig;
         p.has_crf = true;
     }
+    if (!synced) HIPCHK(e, hipStreamSynchronize(s));
     p.prepared = true;
     return PNP_OK;
 }
