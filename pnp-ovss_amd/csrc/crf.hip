@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
                                                          const float* __restrict__ norm_g, const float* __restrict__ norm_b,
                                                          const float* __restrict__ unary, float* __restrict__ Q, float w_g,
                                                          float w_b, float alpha_g, float alpha_b, int pairwise, int img0,
-                                                         int nimg, int tp_cap) {
+                                                         int nimg, int tp_cap, const CrfLabelOut lout) {
     extern __shared__ __attribute__((aligned(16))) float tile[];        // [TP][Kp + 1], then the slice records [TP][20]
     // XCD-affine sweep like the splat / blur kernels: the slice gathers of an image hit the value rows
     // its XCD has just blurred
@@ -687,6 +687,20 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
                     s = __fadd_rn(s, e);
                 }
                 for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
+                if (lout.lab[grp]) {
+                    // last iteration: the label of this (pixel, group) straight from the marginals in LDS -- first maximum,
+                    // NaN counts as maximum (np.argmax, as argmax_kernel reads them back from memory) -- through the LUT
+                    int best = 0;
+                    float bv = row[0];
+                    for (int k = 1; k < K; k++) {
+                        const float v = row[k];
+                        if (bv == bv && (v > bv || v != v)) {
+                            best = k;
+                            bv = v;
+                        }
+                    }
+                    lout.lab[grp][lout.label_off[b] + p0 + px] = (uint8_t)lout.lut[b * lout.lut_stride + best];
+                }
                 if (grp == im.G - 1)                                    // pad floats behind the last group stay zero
                     for (int k = im.G * im.Kg; k < Kp; k++) tile[px * ldt + k] = 0.f;
             }
@@ -975,7 +989,7 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
 // Q <- softmax(-U - pairwise terms) (pairwise != 0) or softmax(-U) (pairwise == 0)
 int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
                const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
-               float w_b, int pairwise, int max_pixels, int max_kp, int groups, hipStream_t s) {
+               float w_b, int pairwise, int max_pixels, int max_kp, int groups, hipStream_t s, const CrfLabelOut& labels) {
     // tile + per-pixel slice records; wide rows (150 classes) take fewer pixels per tile to stay inside the CU's 160 KB
     size_t tp = (size_t)(CRF_TP / (groups > 0 ? groups : 1));
     const size_t per_pixel = ((size_t)max_kp + 1 + 20) * sizeof(float);
@@ -1007,7 +1021,7 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
         }
     }
     hipLaunchKernelGGL(crf_update_kernel, dim3(nbu), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
-                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp);
+                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp, labels);
     return ok();
 }
 

@@ -1258,9 +1258,12 @@ extern "C" int pnp_blur_minmax(pnp_engine* e, void* stream) {
 }
 
 // mean-field iterations over the unary rows already in p.unary; desc = single- or two-group descriptors
-static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s);
+static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s,
+                            const CrfLabelOut& labels);
 
-static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s) {
+// labels: when set, the last update also writes the label maps (argmax + LUT fused into it: no separate pass over Q)
+static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s,
+                       const CrfLabelOut& labels = CrfLabelOut()) {
     auto& pf = e->crf_prof;
     const bool timed = pf.on && pf.used < 4096;
     if (timed) {
@@ -1272,7 +1275,7 @@ static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t 
         }
         (void)hipEventRecord(pf.ev0[pf.used], s);
     }
-    const int r = crf_iterate_body(e, desc, kp_max, iters, pos_w, bi_w, s);
+    const int r = crf_iterate_body(e, desc, kp_max, iters, pos_w, bi_w, s, labels);
     if (timed) {
         (void)hipEventRecord(pf.ev1[pf.used], s);
         pf.used++;
@@ -1287,7 +1290,8 @@ static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t 
     return r;
 }
 
-static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s) {
+static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t iters, float pos_w, float bi_w, hipStream_t s,
+                            const CrfLabelOut& labels) {
     auto& p = e->post;
     const int groups = desc == p.d_desc_pair ? 2 : 1;
     for (int c0 = 0; c0 < p.B; c0 += p.chunk) {
@@ -1299,7 +1303,7 @@ static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int
             KCHK(e, crf_filter(p.lat[0], desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, kp_max, s));
             KCHK(e, crf_filter(p.lat[1], desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, kp_max, s));
             KCHK(e, crf_update(p.lat[0], p.lat[1], desc, c0, n, rg, rb, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 1,
-                               p.maxHW, kp_max, groups, s));
+                               p.maxHW, kp_max, groups, s, it == iters - 1 ? labels : CrfLabelOut()));
         }
     }
     return PNP_OK;
@@ -1373,12 +1377,17 @@ extern "C" int pnp_postprocess_pair(pnp_engine* e, const float* d_gradcam_1drop,
         if (r) return r;
         KCHK(e, unary_from_maps(p.maps2, p.d_desc_pair, p.unary, p.B, p.maxHW, p.maxKp, grp, s));
     }
-    int r = crf_iterate(e, p.d_desc_pair, p.Kpmax_pair, 10, 7.0f, 10.0f, s);
+    CrfLabelOut lout;
+    lout.lab[0] = d_labels_1drop;
+    lout.lab[1] = d_labels_ndrop;
+    lout.lut = p.d_lut;
+    lout.lut_stride = p.lut_stride;
+    lout.label_off = p.d_label_off;
+    int r = crf_iterate(e, p.d_desc_pair, p.Kpmax_pair, 10, 7.0f, 10.0f, s, lout);
     if (r) return r;
     for (int grp = 0; grp < 2; grp++) {
         uint8_t* lab = grp == 0 ? d_labels_1drop : d_labels_ndrop;
         unsigned long long* hist = grp == 0 ? d_hist_1drop : d_hist_ndrop;
-        KCHK(e, argmax_remap(p.Q, p.d_desc_pair, p.d_lut, p.lut_stride, lab, p.d_label_off, 1, grp, p.B, p.maxHW, s));
         if (hist && p.d_gt) KCHK(e, confusion_hist(lab, p.d_gt, p.d_desc, p.d_label_off, hist, n_class, p.B, p.maxHW, s));
     }
     return PNP_OK;

@@ -146,8 +146,16 @@ int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max
                      float* norm_out, hipStream_t s);
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
                float* va, float* vb, const float** result, int max_kp, hipStream_t s);
+// label output of the LAST mean-field update (argmax over the marginals it has just normalised, np.argmax semantics, remapped
+// through the per-image LUT): lab[g] = label map of channel group g, null = no labels from this launch
+struct CrfLabelOut {
+    uint8_t* lab[2] = {nullptr, nullptr};
+    const int32_t* lut = nullptr;
+    int lut_stride = 0;
+    const size_t* label_off = nullptr;
+};
 int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_imgs, int img0, int nimg, const float* vg,
                const float* vb, const float* norm_g, const float* norm_b, const float* unary, float* Q, float w_g,
-               float w_b, int pairwise, int max_pixels, int max_kp, int groups, hipStream_t s);
+               float w_b, int pairwise, int max_pixels, int max_kp, int groups, hipStream_t s, const CrfLabelOut& labels = CrfLabelOut());
 
 }  // namespace pnp
