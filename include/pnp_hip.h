@@ -13,8 +13,10 @@
  *   - All device memory the engine needs is allocated in pnp_create / pnp_post_reserve; the hot
  *     path calls allocate nothing and never synchronise the device (hipGraph-capturable) except
  *     where stated.
- *   - One engine per device per process; an engine is not thread-safe; engines are independent
- *     (matches the one-process-per-GPU model of PnP.py:1439).
+ *   - One process per device (PnP.py:1439).  An engine is not thread-safe: calls on one engine must not overlap.  Distinct
+ *     engines of a process are independent (own workspace, caller's stream) and may be driven concurrently from different
+ *     host threads: that is how a host keeps several batches in flight on one GPU (bench.py --pipelines, the CLI's
+ *     --pipelines; tests/test_hip_parity.py::test_engines_in_flight_match_one_at_a_time).
  */
 #ifndef PNP_HIP_H
 #define PNP_HIP_H

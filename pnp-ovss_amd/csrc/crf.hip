@@ -8,8 +8,12 @@
 // sorted unique keys.  Because the sort is stable, each lattice point's contributor list is in
 // ascending pixel order, so the splat is a gather that adds in exactly the order of the sequential
 // CPU algorithm: results are run-to-run deterministic and bit-comparable with the oracle
-// (oracle/densecrf_ref.c).  All images of a batch go through every kernel together
-// (blockIdx.y = image).  HBM-bound: values are streamed, nothing is reshaped into a GEMM.
+// (oracle/densecrf_ref.c).  All images of a batch go through every kernel together (build kernels:
+// blockIdx.y = image; iteration kernels: whole images per XCD, grids sized to what is resident).
+// Nothing is reshaped into a GEMM: the iteration kernels stream 176..608-byte value rows through gathers and are
+// bound by memory latency x occupancy and by vector-memory issue, so they are written around
+// their dependent-load chains: contributor / neighbour / slice records, requests of the next item behind the
+// gathers of the current one, results stored one item later.
 #include <hipcub/hipcub.hpp>
 
 #include <mutex>
@@ -948,8 +952,9 @@ int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max
     return ok();
 }
 
-// lattice(norm * Q) for images [img0, img0+nimg): splat + (d+1) blurs.  Returns the buffer holding the result.
-int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
+// lattice(norm * Q) for images [img0, img0+nimg): splat + (d+1) blurs (the normaliser rides in the contributor records).
+// Returns the buffer holding the result.
+int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q,
                float* va, float* vb, const float** result, int max_kp, hipStream_t s) {
     const int D = L.D1 - 1;
     const int k4 = (max_kp + 3) / 4;

@@ -1300,8 +1300,8 @@ static int crf_iterate_body(pnp_engine* e, const PostDesc* desc, int kp_max, int
                            p.maxHW, kp_max, groups, s));
         for (int it = 0; it < iters; it++) {
             const float *rg = nullptr, *rb = nullptr;
-            KCHK(e, crf_filter(p.lat[0], desc, c0, n, p.Q, p.norm[0], p.vga, p.vgb, &rg, kp_max, s));
-            KCHK(e, crf_filter(p.lat[1], desc, c0, n, p.Q, p.norm[1], p.va, p.vb, &rb, kp_max, s));
+            KCHK(e, crf_filter(p.lat[0], desc, c0, n, p.Q, p.vga, p.vgb, &rg, kp_max, s));
+            KCHK(e, crf_filter(p.lat[1], desc, c0, n, p.Q, p.va, p.vb, &rb, kp_max, s));
             KCHK(e, crf_update(p.lat[0], p.lat[1], desc, c0, n, rg, rb, p.norm[0], p.norm[1], p.unary, p.Q, pos_w, bi_w, 1,
                                p.maxHW, kp_max, groups, s, it == iters - 1 ? labels : CrfLabelOut()));
         }

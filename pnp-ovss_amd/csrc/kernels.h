@@ -144,7 +144,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
                       void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, hipStream_t s);
 int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, size_t ent_total, float* va, float* vb,
                      float* norm_out, hipStream_t s);
-int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q, const float* norm,
+int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q,
                float* va, float* vb, const float** result, int max_kp, hipStream_t s);
 // label output of the LAST mean-field update (argmax over the marginals it has just normalised, np.argmax semantics, remapped
 // through the per-image LUT): lab[g] = label map of channel group g, null = no labels from this launch
