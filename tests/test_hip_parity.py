@@ -1048,6 +1048,17 @@ def test_postprocess_many_channels_bit_exact_vs_oracle(n_sel, n_class, data_type
         np.testing.assert_array_equal(crf_labels[b].cpu().numpy().astype(np.float32), ref_l)
     _, ref_hist = OP.scores(gts, ref_labels, n_class)
     np.testing.assert_array_equal(hist.cpu().numpy().reshape(n_class, n_class), ref_hist.astype(np.int64))
+    # the paired run at these widths (rows of 120 / 164 / 304 floats: the splat's one-pass and multi-pass forms, the update's
+    # LDS-capped tiles, labels from the last update) against two single runs on the same prepared batch
+    maps_n = maps + (rng.random(maps.shape, dtype=np.float32) ** 3) * (maps > 0)
+    d1, dn = _dev(maps), _dev(maps_n)
+    h1, hn, p1, pn = (torch.zeros(n_class * n_class, device="cuda", dtype=torch.int64) for _ in range(4))
+    ref1 = e.postprocess(d1, 0.15, True, "blur+crf", n_class, h1).clone()
+    refn = e.postprocess(dn, 0.15, False, "blur+crf", n_class, hn).clone()
+    got1, gotn = e.postprocess_pair(d1, dn, 0.15, n_class, p1, pn)
+    torch.cuda.synchronize()
+    assert torch.equal(got1, ref1) and torch.equal(gotn, refn)
+    assert torch.equal(p1, h1) and torch.equal(pn, hn)
     e.close()
 
 
