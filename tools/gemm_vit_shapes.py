@@ -35,5 +35,6 @@ run(M, 3072, 1024, True, False, False, True, 0, "qkv  bf16 out, bias")
 run(M, 4096, 1024, True, False, False, True, 1, "fc1  bf16 out, bias+gelu")
 run(M, 1024, 4096, True, True, True, False, 0, "fc2  f32 out, bias+resid")
 run(M, 1024, 1024, True, True, True, False, 0, "proj f32 out, bias+resid")
+run(M, 9216, 1024, True, False, False, True, 0, "cross K (12 layers x 768), bias", check=False)
 run(1000, 1000, 64, True, False, True, False, 0, "edge M,N ragged, K=64")
 run(300, 520, 192, False, False, False, True, 0, "edge small")
