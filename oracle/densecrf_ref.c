@@ -12,6 +12,11 @@
  * compatibility; DIAG_KERNEL; NORMALIZE_SYMMETRIC with norm = 1/sqrt(K*1 + 1e-20)) and is anchored
  * on the reference's call site only.  exp/log are include/pnp_math.h's fixed fmaf sequences (Eigen's
  * vectorised exp is not reproducible anyway) so the HIP path can be compared bit-for-bit.
+ * Known open point of the restatement (from the published sources as remembered; not checkable in this container): densecrf's
+ * Permutohedral::compute has a scalar path, followed here (the blur is `old + 0.5 * (n1 + n2)` with a double literal, i.e. one
+ * rounding to float per axis), and an SSE path with the same structure in float32 throughout (`0.5f * (n1 + n2)` rounded before
+ * the add: two roundings), taken for more than two channels in SSE builds.  The two differ in last bits per axis pass; which one
+ * a given pydensecrf build runs is part of what tests/golden/make_crf_golden.py pins when the package is available.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off).
  */
