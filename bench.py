@@ -44,8 +44,8 @@ HBM_PEAK_GBS = 8000.0
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=35, help="images per step per GPU (--batch_size 35, Run_seg.sh)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "bf16x3"],
                     help="bf16: throughput mode (BASELINE config 2); f32: the reference's arithmetic; bf16x3: split-bf16, "
