@@ -13,6 +13,8 @@
 // columns of one row: the epilogue does one 8/16-byte store per fragment and vector bias loads.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -385,11 +387,13 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 // EPI: 0 = +bias -> bf16 | 1 = +bias, GELU -> bf16 | 2 = +bias +residual -> fp32 |
 //      3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (transposed cross-attention K / V)
 //      4 = +bias -> fp32 | 5 = as 3 with fp32 output | 6 = +bias, GELU (erf form) -> split bf16 pair (hi, lo)
-// X3 (split-bf16, "bf16x3"): the operands are bf16 pairs a = a_hi + a_lo, b = b_hi + b_lo and the k loop runs three
-// times over K -- (a_hi, b_hi), (a_hi, b_lo), (a_lo, b_hi) -- into the same fp32 accumulators: an fp32-class product
-// (terms dropped: a_lo.b_lo, 2^-18 relative, and what two bf16 cannot hold of an fp32 operand, 2^-17) at a third of
-// the bf16 MFMA rate, i.e. ~5x the fp32 MFMA rate (v_mfma_f32_16x16x4_f32 runs at 1/16 of bf16).  Only the slab ->
-// source-array map of the DMA changes; the MFMA stream is the bf16 kernel's.
+// X3 (split-bf16, "bf16x3"): the operands are bf16 pairs a = a_hi + a_lo, b = b_hi + b_lo and every k16 sub-step issues
+// three MFMAs per fragment pair -- (a_hi, b_lo), (a_lo, b_hi), (a_hi, b_hi) -- into the same fp32 accumulator: an fp32-class
+// product (terms dropped: a_lo.b_lo, 2^-18 relative, and what two bf16 cannot hold of an fp32 operand, 2^-17) at a third of
+// the bf16 MFMA rate, i.e. ~5x the fp32 MFMA rate (v_mfma_f32_16x16x4_f32 runs at 1/16 of bf16).  ONE sweep over K: a ring
+// slot holds a 32-deep k-slab of all four arrays (A_hi | A_lo | B_hi | B_lo, 256 rows x 64 bytes each); per slab a wave
+// issues 48 MFMAs on 24 fragment reads and 8 DMA pieces (the three-sweep form this replaces moved every hi slab twice: 6
+// operand slabs per k-step where 4 suffice, and paid the barrier / hand-over three times).
 //      7 = +bias -> split bf16 pair
 enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3, WIDE_BIAS_F32 = 4, WIDE_TOKCOLS_F32 = 5,
        WIDE_GELU_SPLIT = 6, WIDE_SPLIT = 7 };
@@ -411,51 +415,71 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     const int wm = wave >> 2, wn = wave & 3;
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const int ntiles = nbm * nbn;
-    const int nk0 = g.K / BK;
-    const int nk = X3 ? 3 * nk0 : nk0;
+    // X3: a slab is 32 k-values of the hi AND the lo array of each operand.  Slot image: four 16 KB arrays
+    // A_hi | A_lo | B_hi | B_lo of 256 rows x 64 bytes (4 chunks of 16 B, chunk ^= (row >> 2) & 3: the 16 lanes a
+    // ds_read_b128 services together hit 16 different 16-byte slots of the 256-byte bank row).  A DMA piece is 16 rows
+    // of ONE array (uniform base, per-lane 32-bit offset), so a wave's hi and lo piece of the same rows share an offset.
+    const int nk = X3 ? g.K / 32 : g.K / BK;
     const char* Ab = reinterpret_cast<const char*>(g.A);
     const char* Bb = reinterpret_cast<const char*>(g.B);
     const char* Alo = reinterpret_cast<const char*>(g.A_lo);
     const char* Blo = reinterpret_cast<const char*>(g.B_lo);
 
-    uint32_t soff[NDMA];
+    uint32_t soff[X3 ? 4 : NDMA];
     auto set_tile = [&](int tile, int& m0, int& n0) {
         int bm, bn;
         tile_coords<4>(tile, nbm, nbn, bm, bn);
         m0 = bm * BM;
         n0 = bn * BN;
         const uint32_t lda_b = (uint32_t)g.lda * 2, ldb_b = (uint32_t)g.ldb * 2;
-        const int pc = lane & 7;
+        if constexpr (X3) {
 #pragma unroll
-        for (int i = 0; i < A_DMA; i++) {
-            const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
-            int gr = m0 + row;
-            gr = gr < g.M ? gr : g.M - 1;
-            soff[i] = (uint32_t)gr * lda_b + swz_chunk<ROWB>(row, pc) * 16;
-        }
+            for (int i = 0; i < 2; i++) {                    // two 16-row groups per wave and operand
+                const int row = (wave * 2 + i) * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 2) & 3);    // logical chunk this lane's 16 bytes land as
+                int gr = m0 + row;
+                gr = gr < g.M ? gr : g.M - 1;
+                soff[i] = (uint32_t)gr * lda_b + c * 16;
+                gr = n0 + row;
+                gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
+                soff[2 + i] = (uint32_t)gr * ldb_b + c * 16;
+            }
+        } else {
+            const int pc = lane & 7;
 #pragma unroll
-        for (int i = 0; i < B_DMA; i++) {
-            const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
-            int gr = n0 + row;
-            gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
-            soff[A_DMA + i] = (uint32_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
+            for (int i = 0; i < A_DMA; i++) {
+                const int row = (wave * A_DMA + i) * 8 + (lane >> 3);
+                int gr = m0 + row;
+                gr = gr < g.M ? gr : g.M - 1;
+                soff[i] = (uint32_t)gr * lda_b + swz_chunk<ROWB>(row, pc) * 16;
+            }
+#pragma unroll
+            for (int i = 0; i < B_DMA; i++) {
+                const int row = (wave * B_DMA + i) * 8 + (lane >> 3);
+                int gr = n0 + row;
+                gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
+                soff[A_DMA + i] = (uint32_t)gr * ldb_b + swz_chunk<ROWB>(row, pc) * 16;
+            }
         }
     };
     auto issue_one = [&](int kt, int i) {
+#ifdef PNP_DEV
+        if (g.ablate == 1 && kt >= 2) return;           // timing ablation: no steady-state DMA
+#endif
         char* stage = smem + (kt & 1) * STAGE;
-        int kk = kt;
-        const char *abase = Ab, *bbase = Bb;
-        if constexpr (X3) {                         // slab kt of 3 nk0: (hi, hi) | (hi, lo) | (lo, hi) over the same K
-            const int seg = kt >= 2 * nk0 ? 2 : (kt >= nk0 ? 1 : 0);
-            kk = kt - seg * nk0;
-            abase = seg == 2 ? Alo : Ab;
-            bbase = seg == 1 ? Blo : Bb;
+        if constexpr (X3) {                         // piece i: operand = i >> 2, row group = (i >> 1) & 1, array (hi | lo) = i & 1
+            const int op = i >> 2, rg = (i >> 1) & 1, lo = i & 1;
+            const char* base = op ? (lo ? Blo : Bb) : (lo ? Alo : Ab);
+            const int d = op * 32768 + lo * 16384 + (wave * 2 + rg) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[op * 2 + rg] + (uint32_t)kt * 64)),
+                                             (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
+        } else {
+            const uint32_t koff = (uint32_t)kt * ROWB;
+            const char* base = i < A_DMA ? Ab : Bb;
+            const int d = i < A_DMA ? (wave * A_DMA + i) * 8 * ROWB : BM * ROWB + (wave * B_DMA + (i - A_DMA)) * 8 * ROWB;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[i] + koff)),
+                                             (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
         }
-        const uint32_t koff = (uint32_t)kk * ROWB;
-        const char* base = i < A_DMA ? abase : bbase;
-        const int d = i < A_DMA ? (wave * A_DMA + i) * 8 * ROWB : BM * ROWB + (wave * B_DMA + (i - A_DMA)) * 8 * ROWB;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[i] + koff)),
-                                         (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
     };
     auto stamp = [&](int slot) {
         if (g.stamps && tid == 0) {
@@ -466,8 +490,9 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 
     // fragment addresses: row = tile row + l32, logical chunk = 2 ks + hi; the swizzle term depends on
     // l32 only (tile row offsets are multiples of 32), so one XOR per k16 sub-step serves all tiles
-    const int sw = (l32 >> 1) & 7;
-    const int a_row_off = (wm * 128 + l32) * ROWB, b_row_off = BM * ROWB + (wn * 64 + l32) * ROWB;
+    const int sw = X3 ? (l32 >> 2) & 3 : (l32 >> 1) & 7;
+    const int a_row_off = X3 ? (wm * 128 + l32) * 64 : (wm * 128 + l32) * ROWB;
+    const int b_row_off = X3 ? 32768 + (wn * 64 + l32) * 64 : BM * ROWB + (wn * 64 + l32) * ROWB;
     float* const stg = reinterpret_cast<float*>(smem + 65536) + wave * (32 * SROW);
 
     int tile = blockIdx.x;
@@ -521,61 +546,148 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         if (drain32) PNP_WAIT_VM(32);
         else PNP_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();               // slab 0 complete; staging area (slot 1) no longer read
-        if (nk > 1) {
+        if constexpr (X3) {
+            // Split-bf16 main loop.  Slab = 32 k of (A_hi | A_lo) and (B_hi | B_lo); two k16 sub-steps of 24 MFMAs per wave.
+            // The A fragments (hi, lo) of row tile j are dead after its six MFMAs and are refilled in place with the next
+            // sub-step's; only the B fragments are double-buffered (192 of the 256 registers: 128 accumulators + 64 fragment).
+            // Hand-over as in the bf16 loop: the barrier sits in front of a slab's LAST sub-step, whose operands are in
+            // registers, so its MFMAs cover the barrier, the DMA issue of slab t+2 and the first reads of slab t+1.
+            bf16x8 ah[TM - 1], al[TM - 1], xh0, xl0, xh1, xl1, bh0[TN], bl0[TN], bh1[TN], bl1[TN];
+            auto rd_a = [&](bf16x8& h, bf16x8& l, int kt, int ks, int j) {
+                const char* st = smem + (kt & 1) * STAGE + a_row_off + j * 2048 + (((ks * 2 + hi) ^ sw) << 4);
+                h = *reinterpret_cast<const bf16x8*>(st);
+                l = *reinterpret_cast<const bf16x8*>(st + 16384);
+            };
+            auto rd_b = [&](bf16x8* bh, bf16x8* bl, int kt, int ks, int i) {
+                const char* st = smem + (kt & 1) * STAGE + b_row_off + i * 2048 + (((ks * 2 + hi) ^ sw) << 4);
+                bh[i] = *reinterpret_cast<const bf16x8*>(st);
+                bl[i] = *reinterpret_cast<const bf16x8*>(st + 16384);
+            };
+            // one sub-step on (ah, al, [xh, xl], bh, bl), small terms first; REFILL: the next sub-step's fragments from
+            // (kt_n, ks_n) -- row tiles 0..2 in place behind their MFMAs, the last row tile into the other of its two register
+            // sets (xhn, xln) right behind the first tile's MFMAs (so no read is issued behind the last MFMAs of a sub-step
+            // and the wait in front of the barrier finds every read long complete), B into (bhn, bln); DMA: the 8 pieces of
+            // slab kt_d, two behind each row tile's MFMAs
+            auto sub = [&](const bf16x8& xh, const bf16x8& xl, bf16x8& xhn, bf16x8& xln, const bf16x8* bh, const bf16x8* bl, bf16x8* bhn,
+                           bf16x8* bln, int kt_n, int ks_n, auto refill, auto dma, int kt_d) {
 #pragma unroll
-            for (int i = 0; i < NDMA; i++) issue_one(1, i);
-        }
-        bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-        read_frags(fa0, fb0, 0, 0);
-        // sub-steps s0..s2 of slab kt: MFMAs on one fragment set, reads of the next sub-step into the other
-        auto body012 = [&](int kt) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            read_frags(fa1, fb1, kt, 1);
-            mma_all(fa0, fb0);
-            sched_plain();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            read_frags(fa0, fb0, kt, 2);
-            mma_all(fa1, fb1);
-            sched_plain();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            read_frags(fa1, fb1, kt, 3);
-            mma_all(fa0, fb0);
-            sched_plain();
-        };
-        int kt = 0;
-        for (; kt + 2 < nk; kt++) {                 // steady state: slab kt+2 exists
-            body012(kt);
-            PNP_WAIT_VM_LGKM(0);                    // own s3 fragments in registers, own pieces of slab kt+1 landed
-            __builtin_amdgcn_s_barrier();           // slab kt+1 complete; nobody reads slab kt's slot any more
-            read_frags(fa0, fb0, kt + 1, 0);
+                for (int j = 0; j < TM; j++) {
+                    const bf16x8& fh = j < TM - 1 ? ah[j < TM - 1 ? j : 0] : xh;
+                    const bf16x8& fl = j < TM - 1 ? al[j < TM - 1 ? j : 0] : xl;
 #pragma unroll
-            for (int i = 0; i < NDMA; i++) issue_one(kt + 2, i);
-            mma_all(fa1, fb1);
-            // LDS-DMA writes may not be reordered against the LDS reads: reads lead, DMA pieces follow
+                    for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[i], fh, acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], fl, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], fh, acc[i][j], 0, 0, 0);
+                    if constexpr (decltype(dma)::value) {
+                        issue_one(kt_d, 2 * j);
+                        issue_one(kt_d, 2 * j + 1);
+                    }
+                    if constexpr (decltype(refill)::value) {
+                        if (j < TM - 1) rd_a(ah[j < TM - 1 ? j : 0], al[j < TM - 1 ? j : 0], kt_n, ks_n, j);
+                        if (j == 0) rd_a(xhn, xln, kt_n, ks_n, TM - 1);
+                        if (j == 1) {
+                            rd_b(bhn, bln, kt_n, ks_n, 0);
+                            rd_b(bhn, bln, kt_n, ks_n, 1);
+                        }
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    if constexpr (decltype(dma)::value) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    if constexpr (decltype(refill)::value) {
+                        if (j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        else if (j == 1) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                        else if (j == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    }
+                }
+            };
+            constexpr std::true_type yes{};
+            constexpr std::false_type no{};
+#pragma unroll
+            for (int i = 0; i < NDMA; i++) issue_one(1, i);     // nk >= 2
+#pragma unroll
+            for (int j = 0; j < TM - 1; j++) rd_a(ah[j], al[j], 0, 0, j);
+            rd_a(xh0, xl0, 0, 0, TM - 1);
+#pragma unroll
+            for (int i = 0; i < TN; i++) rd_b(bh0, bl0, 0, 0, i);
+            // sub-step 0 of a slab works on (x0, b0) and refills (x1, b1) from the same slab's second half; sub-step 1 works on
+            // (x1, b1) and refills (x0, b0) from the next slab.  The compiler's counted lgkmcnt waits cover the register
+            // dependencies; only the wait in front of the barrier is explicit (the slot is about to be overwritten)
+            int kt = 0;
+            for (; kt + 2 < nk; kt++) {                 // steady state: slab kt+2 exists
+                sub(xh0, xl0, xh1, xl1, bh0, bl0, bh1, bl1, kt, 1, yes, no, 0);
+                __builtin_amdgcn_sched_barrier(0);      // keep the sub-step's last MFMAs in front of the wait
+                PNP_WAIT_VM_LGKM(0);                    // own reads of slab kt complete, own pieces of slab kt+1 landed
+                __builtin_amdgcn_s_barrier();           // slab kt+1 complete; nobody reads slab kt's slot any more
+                __builtin_amdgcn_sched_barrier(0);
+                sub(xh1, xl1, xh0, xl0, bh1, bl1, bh0, bl0, kt + 1, 0, yes, yes, kt + 2);
             }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
-        if (kt + 1 < nk) {                          // second-to-last slab: nothing left to fetch
-            body012(kt);
+            sub(xh0, xl0, xh1, xl1, bh0, bl0, bh1, bl1, kt, 1, yes, no, 0);   // second-to-last slab: nothing left to fetch
+            __builtin_amdgcn_sched_barrier(0);
             PNP_WAIT_VM_LGKM(0);
             __builtin_amdgcn_s_barrier();
-            read_frags(fa0, fb0, kt + 1, 0);
-            mma_all(fa1, fb1);
-            sched_plain();
+            __builtin_amdgcn_sched_barrier(0);
+            sub(xh1, xl1, xh0, xl0, bh1, bl1, bh0, bl0, kt + 1, 0, yes, no, 0);
             kt++;
+            sub(xh0, xl0, xh1, xl1, bh0, bl0, bh1, bl1, kt, 1, yes, no, 0);   // last slab
+            sub(xh1, xl1, xh0, xl0, bh1, bl1, bh0, bl0, 0, 0, no, no, 0);
+        } else {
+            if (nk > 1) {
+    #pragma unroll
+                for (int i = 0; i < NDMA; i++) issue_one(1, i);
+            }
+            bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+            read_frags(fa0, fb0, 0, 0);
+            // sub-steps s0..s2 of slab kt: MFMAs on one fragment set, reads of the next sub-step into the other
+            auto body012 = [&](int kt) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                read_frags(fa1, fb1, kt, 1);
+                mma_all(fa0, fb0);
+                sched_plain();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                read_frags(fa0, fb0, kt, 2);
+                mma_all(fa1, fb1);
+                sched_plain();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                read_frags(fa1, fb1, kt, 3);
+                mma_all(fa0, fb0);
+                sched_plain();
+            };
+            int kt = 0;
+            for (; kt + 2 < nk; kt++) {                 // steady state: slab kt+2 exists
+                body012(kt);
+                PNP_WAIT_VM_LGKM(0);                    // own s3 fragments in registers, own pieces of slab kt+1 landed
+                __builtin_amdgcn_s_barrier();           // slab kt+1 complete; nobody reads slab kt's slot any more
+                read_frags(fa0, fb0, kt + 1, 0);
+    #pragma unroll
+                for (int i = 0; i < NDMA; i++) issue_one(kt + 2, i);
+                mma_all(fa1, fb1);
+                // LDS-DMA writes may not be reordered against the LDS reads: reads lead, DMA pieces follow
+    #pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+    #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            if (kt + 1 < nk) {                          // second-to-last slab: nothing left to fetch
+                body012(kt);
+                PNP_WAIT_VM_LGKM(0);
+                __builtin_amdgcn_s_barrier();
+                read_frags(fa0, fb0, kt + 1, 0);
+                mma_all(fa1, fb1);
+                sched_plain();
+                kt++;
+            }
+            body012(kt);                                // last slab
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            mma_all(fa1, fb1);
         }
-        body012(kt);                                // last slab
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        mma_all(fa1, fb1);
         if (tile == (int)blockIdx.x) stamp(2);
 
         __syncthreads();                            // every wave is done reading the last slab: both slots are free

@@ -38,10 +38,13 @@ class BlipCaptionProcessor:
 
 
 def load_model_and_preprocess(name, model_type, is_eval=False, device="cpu", **kw):
-    """Same call as PnP_OVSS_0514_updated_segmentation.py:1212-1213.  Extra keyword arguments
-    (img_size, max_batch, stash_layer, bf16, checkpoint, vocab, ...) go to pnp_ovss.model.build_model."""
+    """Same call as PnP_OVSS_0514_updated_segmentation.py:1212-1213.  With only the reference's arguments the model
+    is built lazily in the parity mode (fp32 arithmetic) and takes its geometry from the first
+    compute_gradcam_ensemble(args, ...) call; extra keyword arguments (img_size, max_batch, stash_layer, mode,
+    checkpoint, vocab, ...) go to pnp_ovss.model.build_model and size the engine at once."""
     if name != "blip_image_text_matching":
         raise ValueError(f"unknown model {name!r}: only blip_image_text_matching is on the hot path")
     model = build_model(model_type=model_type, device=device, **kw)
-    size = kw.get("img_size", 336)
-    return model, {"eval": BlipImageEvalProcessor(size)}, {"eval": BlipCaptionProcessor()}
+    if is_eval:
+        model.eval()
+    return model, {"eval": BlipImageEvalProcessor(model.cfg.img_size)}, {"eval": BlipCaptionProcessor()}

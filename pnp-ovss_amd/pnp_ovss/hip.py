@@ -274,9 +274,10 @@ class Engine:
 
     MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
 
-    def __init__(self, cfg, max_batch, max_text_len=64, stash_layer=7, bf16=True, device=0, mode=None):
-        """mode: "f32" (the reference's arithmetic), "bf16" (throughput), "bf16x3" (split-bf16: fp32-class results on the
-        bf16 MFMA); `bf16=True/False` is the older spelling of "bf16" / "f32"."""
+    def __init__(self, cfg, max_batch, max_text_len=64, stash_layer=7, bf16=False, device=0, mode=None):
+        """mode: "f32" (the reference's arithmetic; the default), "bf16x3" (split-bf16: fp32-class results on the bf16
+        MFMA), "bf16" (throughput; does not reproduce the reference's patch picks); `bf16=True/False` is the older
+        spelling of "bf16" / "f32"."""
         if not torch.cuda.is_available():
             raise RuntimeError("pnp_ovss.hip.Engine needs a HIP device (no CPU fallback)")
         self.lib = load_library()

@@ -53,11 +53,27 @@ class _Obj:
     pass
 
 
-class BlipITM:
-    """BLIP image-text matching model whose forward / GradCAM run in libpnp_hip.so."""
+class BlipITM(torch.nn.Module):
+    """BLIP image-text matching model whose forward / GradCAM run in libpnp_hip.so.
 
-    def __init__(self, cfg, engine, tokenizer):
-        self.cfg, self.engine, self.tokenizer = cfg, engine, tokenizer
+    An `nn.Module` so that the reference driver's `DDP(model, device_ids=[rank])` (PnP.py:1218) accepts it: DDP needs one
+    parameter that requires grad (`ddp_anchor`, never used) and broadcasts the parameters AND buffers of rank 0 at
+    construction -- which is the reference's weight broadcast, so a lazily built model keeps its fp32 weights in buffers
+    (`weights_flat`, `pos_embed_raw`) until the engine is created.
+
+    Two ways to get one (build_model): eager -- geometry, batch, text length, stash layer and compute mode given, engine
+    created at once (CLI, bench, tests) -- or lazy: the reference's literal
+    `load_model_and_preprocess("blip_image_text_matching", "large", device=rank, is_eval=True)` carries none of them, so
+    the engine is created by the first `compute_gradcam_ensemble(args, ...)` / `drop_loop(args, ...)` / forward call from
+    `args.img_size` (B/blip_image_text_matching.py:408), `args.max_att_block_num`, `args.batch_size` and the batch at hand,
+    in the parity mode ("f32" unless PNP_OVSS_DTYPE says otherwise), and re-created if a later call does not fit it."""
+
+    def __init__(self, cfg, engine, tokenizer, lazy=None, device=None):
+        super().__init__()
+        self.cfg, self.tokenizer = cfg, tokenizer
+        self._engine = engine
+        self._lazy = lazy                                          # None (eager) or dict(mode=, seed=, index=)
+        self._device = torch.device("cuda", device if device is not None else 0) if engine is None else engine.device
         self.max_txt_len = 500                                     # blip_image_text_matching.py:48
         layers = []
         for i in range(cfg.txt_layers):
@@ -75,23 +91,63 @@ class BlipITM:
         self.text_encoder.base_model = bm1
         self.visual_encoder = _Obj()
         self.visual_encoder.vision_width = cfg.vit_dim
-        self.module = self                                         # DDP-wrapper attribute the driver dereferences
+        self.ddp_anchor = torch.nn.Parameter(torch.zeros(1, device=self._device))
         self._last = None
         self._grad_layer = None
 
-    # nn.Module-ish no-ops the driver calls
-    def eval(self):
+    @property
+    def module(self):                                              # `model.module.…` also works without the DDP wrapper
         return self
-
-    def to(self, device):
-        return self
-
-    def zero_grad(self):
-        pass
 
     @property
     def device(self):
-        return self.engine.device
+        return self._engine.device if self._engine is not None else self._device
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self.ensure_engine()
+        return self._engine
+
+    # ------------------------------------------------------------------ lazy engine
+    def ensure_engine(self, img_size=None, batch=None, stash_layer=None, text_len=None):
+        """Create (or, for a lazily built model, re-create) the engine so that it fits the call at hand.  Eager models
+        only check and fail loudly, as before."""
+        eng = self._engine
+        if eng is not None:
+            fits = ((img_size is None or img_size == eng.cfg.img_size) and (batch is None or batch <= eng.max_batch) and
+                    (stash_layer is None or stash_layer >= eng.stash_layer) and (text_len is None or text_len <= eng.max_text_len))
+            if fits:
+                return eng
+            if self._lazy is None:
+                raise RuntimeError(f"engine built for img_size={eng.cfg.img_size}, batch<={eng.max_batch}, text<={eng.max_text_len}, "
+                                   f"layers>={eng.stash_layer}; the call needs img_size={img_size}, batch={batch}, text={text_len}, "
+                                   f"layer={stash_layer}: re-create the model with matching arguments")
+            warnings.warn("re-creating the HIP engine: the call does not fit the one built by the first call")
+            img_size = img_size or eng.cfg.img_size
+            batch = max(batch or 0, eng.max_batch)
+            stash_layer = min(stash_layer if stash_layer is not None else eng.stash_layer, eng.stash_layer)
+            text_len = max(text_len or 0, eng.max_text_len)
+            eng.close()
+            self._engine = None
+        if self._lazy is None:
+            raise RuntimeError("model has no engine")
+        import dataclasses
+        lz = self._lazy
+        cfg = dataclasses.replace(self.cfg, img_size=int(img_size or self.cfg.img_size))
+        if stash_layer is None:
+            stash_layer = int(os.environ.get("PNP_OVSS_STASH_LAYER", 0))      # 0: all 12 x 12 maps, like the reference's return value
+        eng = Engine(cfg, max_batch=int(batch or lz["max_batch"]), max_text_len=min(192, max(64, int(text_len or 0))),
+                     stash_layer=int(stash_layer), mode=lz["mode"], device=self._device.index or 0)
+        flat = self.weights_flat
+        sd = {}
+        for n, (o, shp) in lz["index"].items():
+            sd[n] = flat[o:o + int(np.prod(shp))].view(*shp)
+        sd["visual_encoder.pos_embed"] = _resize_pos_embed(self.pos_embed_raw.cpu(), cfg.grid).to(flat.device)   # base_model.py:108-110
+        eng.load_state_dict(sd)
+        self.cfg, self._engine = cfg, eng
+        self._last = self._grad_layer = None
+        return eng
 
     def _tok_longest(self, captions):
         return self.tokenizer(captions, padding="longest", truncation=True, max_length=self.max_txt_len,
@@ -111,18 +167,34 @@ class BlipITM:
         flat = self.engine.buffer(name)
         return flat[: B * self.cfg.txt_heads * L * nst].view(B, self.cfg.txt_heads, L, nst)[..., :N]
 
-    def __call__(self, samples, match_head="itm"):
+    def forward(self, samples, match_head="itm"):
         """BlipITM.forward(match_head="itm") (blip_image_text_matching.py:217-249) -> logits (B,2)."""
         if match_head != "itm":
             raise NotImplementedError("only the ITM head is on the hot path")
-        image = samples["image"].to(self.device, torch.float32).contiguous()
-        text = self._tok_longest(samples["text_input"]).to(self.device)
+        text = self._tok_longest(samples["text_input"])
         L = text.input_ids.shape[1]
-        self.engine.vit_forward(image)
-        logits = self.engine.text_forward(text.input_ids.contiguous(), text.attention_mask.contiguous(), L)
+        eng = self.ensure_engine(img_size=int(samples["image"].shape[-1]), batch=int(samples["image"].shape[0]), text_len=L)
+        image = samples["image"].to(self.device, torch.float32).contiguous()
+        text = text.to(self.device)
+        eng.vit_forward(image)
+        logits = eng.text_forward(text.input_ids.contiguous(), text.attention_mask.contiguous(), L)
         self._last = (image.shape[0], L)
         self._grad_layer = None
         return logits
+
+
+def _call_geometry(args, m, image, L):
+    """What a call needs of the engine: the reference reads args.img_size inside compute_gradcam_ensemble (B/…:408); the
+    layer it will index is args.max_att_block_num - 1 (PnP.py:619-621); batches come in args.batch_size (PnP.py:59)."""
+    img_size = int(getattr(args, "img_size", 0) or image.shape[-1])
+    if img_size != int(image.shape[-1]):
+        raise ValueError(f"args.img_size={img_size} but the images are {tuple(image.shape)}")
+    layer = getattr(args, "max_att_block_num", None)
+    layer = int(layer) - 1 if layer is not None else None
+    batch = max(int(image.shape[0]), int(getattr(args, "batch_size", 0) or 0))
+    if m._engine is not None and m._lazy is None:
+        layer = None                              # eager engines serve layers >= their stash_layer; the accessors check
+    return m.ensure_engine(img_size=img_size, batch=batch, stash_layer=layer, text_len=L)
 
 
 class _LazyHeads:
@@ -165,10 +237,11 @@ class _LazyBlocks:
 def compute_gradcam_ensemble(args, model, visual_input, text_input, tokenized_text, drop_iter=0):
     """Drop-in for blip_image_text_matching.py:386-457."""
     m = model.module if hasattr(model, "module") else model
-    eng = m.engine
-    image = visual_input.to(m.device, torch.float32).contiguous()
-    text = m._tok_longest(text_input).to(m.device)
+    text = m._tok_longest(text_input)
     L = text.input_ids.shape[1]
+    eng = _call_geometry(args, m, visual_input, L)
+    image = visual_input.to(m.device, torch.float32).contiguous()
+    text = text.to(m.device)
     B = image.shape[0]
     eng.vit_forward(image)
     logits = eng.text_forward(text.input_ids.contiguous(), text.attention_mask.contiguous(), L)
@@ -182,13 +255,14 @@ def compute_gradcam_ensemble(args, model, visual_input, text_input, tokenized_te
 def drop_loop(args, model, txt_tokens, imgs_in, caption_list):
     """Inference_BLIP_filteredcaption (PnP.py:564-722): returns (gradcam_0, gradcam_agg) on device."""
     m = model.module if hasattr(model, "module") else model
-    image = imgs_in.to(m.device, torch.float32).contiguous()
-    text = m._tok_longest(caption_list).to(m.device)
+    text = m._tok_longest(caption_list)
     L = text.input_ids.shape[1]
+    eng = _call_geometry(args, m, imgs_in, L)
+    image = imgs_in.to(m.device, torch.float32).contiguous()
     mask = txt_tokens.attention_mask.to(m.device).contiguous()
     ids = txt_tokens.input_ids.to(m.device).contiguous()
-    layer = int(args.max_att_block_num) - 1 if getattr(args, "max_att_block_num", None) is not None else m.engine.stash_layer
-    g0, agg, picks, _ = m.engine.drop_loop(image, ids, mask, L, int(args.prune_att_head), int(args.drop_iter), layer=layer)
+    layer = int(args.max_att_block_num) - 1 if getattr(args, "max_att_block_num", None) is not None else eng.stash_layer
+    g0, agg, picks, _ = eng.drop_loop(image, ids, mask, L, int(args.prune_att_head), int(args.drop_iter), layer=layer)
     m._last = (image.shape[0], L)
     m._grad_layer = layer
     return g0, agg
@@ -231,31 +305,81 @@ def merge_checkpoint(cfg, ckpt_state, init_state):
     return state, dropped, missing
 
 
-def build_model(model_type="large", img_size=336, device=0, max_batch=35, max_text_len=64, stash_layer=7, bf16=True,
-                checkpoint=None, vocab=None, seed=0, cfg=None, mode=None):
-    """from_config + load_checkpoint (blip_image_text_matching.py:297-314, base_model.py:86-125)."""
+def _model_config(model_type, img_size):
+    """The model yaml of the reference (B/blip_itm_large.yaml + med_large_config.json) as this build reads it: the
+    built-in BLIP-ITM-large geometry, or a JSON file of ModelCfg fields named by PNP_OVSS_MODEL_CONFIG (tests: the
+    reduced geometry of the golden vectors; "weight_seed" selects the seeded synthetic weights)."""
+    path = os.environ.get("PNP_OVSS_MODEL_CONFIG")
+    seed = None
+    if path:
+        import json
+        d = json.load(open(path))
+        seed = d.pop("weight_seed", None)
+        cfg = C.ModelCfg(**d)
+        if img_size:
+            import dataclasses
+            cfg = dataclasses.replace(cfg, img_size=int(img_size))
+        return cfg, seed
+    if model_type != "large":
+        raise ValueError("only blip_image_text_matching/large is on the hot path")
+    return C.blip_itm_large(int(img_size or 336)), seed            # image_size: 336 (blip_itm_large.yaml:17)
+
+
+def build_model(model_type="large", img_size=None, device=0, max_batch=None, max_text_len=None, stash_layer=None, bf16=None,
+                checkpoint=None, vocab=None, seed=None, cfg=None, mode=None):
+    """from_config + load_checkpoint (blip_image_text_matching.py:297-314, base_model.py:86-125).
+
+    With the engine's sizing given (img_size or cfg, max_batch, stash_layer) the engine is created here.  Without -- the
+    reference's own call, PnP.py:1212 -- the model is lazy (see BlipITM): weights are loaded into device buffers now, the
+    engine follows the first call.  Compute mode: `mode` ("f32" | "bf16x3" | "bf16"), else PNP_OVSS_DTYPE, else "f32" --
+    the reference's arithmetic; "bf16" is never a default."""
+    cfg_seed = None
     if cfg is None:
-        if model_type != "large":
-            raise ValueError("only blip_image_text_matching/large is on the hot path")
-        cfg = C.blip_itm_large(img_size)
+        cfg, cfg_seed = _model_config(model_type, img_size)
+    if seed is None:
+        seed = int(cfg_seed if cfg_seed is not None else os.environ.get("PNP_OVSS_SEED", 0))
+    if mode is None:
+        mode = ("bf16" if bf16 else "f32") if bf16 is not None else os.environ.get("PNP_OVSS_DTYPE", "f32")
     checkpoint = checkpoint or os.environ.get("PNP_OVSS_CHECKPOINT")
     vocab = vocab or os.environ.get("PNP_OVSS_VOCAB")
     dev = device if isinstance(device, int) else (torch.device(device).index or 0)
-    eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len, stash_layer=stash_layer, bf16=bf16, device=dev, mode=mode)
+    tok = WordPieceTokenizer(vocab) if vocab else SynthTokenizer(cfg.vocab)
     init = synth.synth_state_dict(cfg, seed)                      # stands in for the module's initialisation
+    eager = max_batch is not None and stash_layer is not None
     if checkpoint:
         sd = torch.load(checkpoint, map_location="cpu")
         sd = sd["model"] if "model" in sd else sd
+        raw_pos = sd.get("visual_encoder.pos_embed")
         state, dropped, missing = merge_checkpoint(cfg, sd, init)
         if dropped or missing:
             warnings.warn(f"checkpoint {checkpoint}: dropped (shape mismatch) {dropped}, not provided {missing}: "
                           f"those tensors keep their initial values, like load_state_dict(strict=False)")
-        eng.load_state_dict(state)
     else:
         warnings.warn("no BLIP checkpoint given (PNP_OVSS_CHECKPOINT): using seeded synthetic weights")
-        eng.load_state_dict(init)
-    tok = WordPieceTokenizer(vocab) if vocab else SynthTokenizer(cfg.vocab)
-    return BlipITM(cfg, eng, tok)
+        state, raw_pos = init, None
+    if eager:
+        eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len or 64, stash_layer=stash_layer, device=dev, mode=mode)
+        eng.load_state_dict(state)
+        return BlipITM(cfg, eng, tok)
+    # lazy: fp32 weights in device buffers (what DDP broadcasts), the checkpoint's own pos_embed grid kept for re-tiling
+    torch.cuda.set_device(dev)
+    index, total = {}, 0
+    for n, t in state.items():
+        if n == "visual_encoder.pos_embed":
+            continue
+        shp = tuple(int(x) for x in np.shape(t))
+        index[n] = (total, shp)
+        total += int(np.prod(shp))
+    flat = torch.empty(total, dtype=torch.float32)
+    for n, (o, shp) in index.items():
+        flat[o:o + int(np.prod(shp))].copy_(torch.as_tensor(np.asarray(state[n]) if not isinstance(state[n], torch.Tensor) else state[n],
+                                                             dtype=torch.float32).reshape(-1))
+    pos = raw_pos if raw_pos is not None else state["visual_encoder.pos_embed"]
+    model = BlipITM(cfg, None, tok, lazy=dict(mode=mode, index=index, max_batch=int(max_batch or 35)), device=dev)
+    model.register_buffer("weights_flat", flat.to(model._device), persistent=False)
+    model.register_buffer("pos_embed_raw", torch.as_tensor(np.asarray(pos) if not isinstance(pos, torch.Tensor) else pos,
+                                                           dtype=torch.float32).to(model._device), persistent=False)
+    return model
 
 
 class Segmenter:

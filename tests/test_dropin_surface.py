@@ -43,6 +43,72 @@ def test_compute_gradcam_ensemble_surface_matches_reference_golden(golden_dir):
     model.engine.close()
 
 
+def test_reference_driver_literal_call_sequence(golden_dir, tmp_path, monkeypatch):
+    """The reference driver's own lines, verbatim, through the import shim: PnP.py:1212-1213 (load_model_and_preprocess with
+    the reference's four arguments and nothing else), :1218 (DDP wrapper), :271 (tokenizer(...).to(rank)), :294-298 (hook
+    flags), :567-575 (compute_gradcam_ensemble under torch.inference_mode(), [layer][head].detach().clone()).  The model must
+    come up in the parity mode (fp32 arithmetic), take its geometry from args.img_size and its kept layer from
+    args.max_att_block_num, and reproduce the reference's own map (gradcam_small.npz).  The model geometry is the "yaml" of
+    this build: PNP_OVSS_MODEL_CONFIG names the reduced configuration the golden vectors were made with."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from pnp_ovss import config as C, synth
+    g = np.load(os.path.join(golden_dir, "gradcam_small.npz"))
+    cfgd = json.loads(str(g["cfg"]))
+    cfg = C.ModelCfg(**cfgd)
+    yaml = dict(cfgd, weight_seed=int(g["weight_seed"]))
+    (tmp_path / "model.json").write_text(json.dumps(yaml))
+    monkeypatch.setenv("PNP_OVSS_MODEL_CONFIG", str(tmp_path / "model.json"))
+    for k in ("PNP_OVSS_DTYPE", "PNP_OVSS_CHECKPOINT", "PNP_OVSS_VOCAB", "PNP_OVSS_STASH_LAYER"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=int(g["image_seed"]))
+    imgs_in = torch.from_numpy(imgs)
+    caption_filtered_list = [str(c) for c in g["captions"]]
+    args = argparse.Namespace(img_size=cfg.img_size, max_att_block_num=8, prune_att_head="9", drop_iter=1, batch_size=2)
+    rank = 0
+    dist.init_process_group("nccl", rank=rank, world_size=1)                   # ddp_setup, PnP.py:45-54
+    try:
+        torch.cuda.set_device(rank)
+        from lavis.models import load_model_and_preprocess
+        from lavis.models.blip_models.blip_image_text_matching import compute_gradcam_ensemble
+        model_textloc, vis_processors_textloc, text_processors_textloc = load_model_and_preprocess(
+            "blip_image_text_matching", "large", device=rank, is_eval=True)
+        assert model_textloc._engine is None                                   # nothing sized yet: the first call decides
+        model_textloc = DDP(model_textloc, device_ids=[rank])
+        txt_tokens = model_textloc.module.tokenizer(caption_filtered_list, padding="max_length", max_length=500,
+                                                    return_tensors="pt").to(rank)
+        np.testing.assert_array_equal(txt_tokens.input_ids.cpu().numpy(), g["input_ids"])
+        for block_num in range(7, 9):
+            model_textloc.module.text_encoder.base_model.base_model.encoder.layer[
+                block_num
+            ].crossattention.self.save_attention = False
+        with torch.inference_mode():
+            gradcam_filterd_ensemble, cam_filterd_ensemble, filterd_output = compute_gradcam_ensemble(args,
+                                                                                                      model_textloc.module,
+                                                                                                      imgs_in.to(rank),
+                                                                                                      caption_filtered_list,
+                                                                                                      txt_tokens)
+            layer = int(args.max_att_block_num) - 1
+            head = int(args.prune_att_head)
+            gradcam_0_filtered = gradcam_filterd_ensemble[layer][head].detach().clone()
+        eng = model_textloc.module.engine
+        assert eng.mode == "f32" and eng.cfg.img_size == cfg.img_size and eng.stash_layer == 7 and eng.max_batch == 2
+        assert cam_filterd_ensemble == [] and gradcam_0_filtered.device.type == "cpu"
+        assert np.abs(gradcam_0_filtered.numpy() - g["maps"][7, 9]).max() < 1e-4
+        np.testing.assert_allclose(filterd_output.cpu().numpy(), g["logits"], atol=5e-3)
+        # a second call with a larger batch / another layer re-creates the engine instead of failing or silently truncating
+        args2 = argparse.Namespace(img_size=cfg.img_size, max_att_block_num=4, prune_att_head="2", drop_iter=1, batch_size=2)
+        with pytest.warns(UserWarning, match="re-creating"):
+            ens2, _, _ = compute_gradcam_ensemble(args2, model_textloc.module, imgs_in.to(rank), caption_filtered_list, txt_tokens)
+        assert np.abs(ens2[3][2].numpy() - g["maps"][3, 2]).max() < 1e-4
+        model_textloc.module.engine.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_cli_synthetic_end_to_end(tmp_path):
     save = tmp_path / "out"
     cmd = [sys.executable, os.path.join(ROOT, "pnp-ovss_amd", "PnP_OVSS_0514_updated_segmentation.py"),
