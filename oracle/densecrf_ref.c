@@ -12,11 +12,12 @@
  * compatibility; DIAG_KERNEL; NORMALIZE_SYMMETRIC with norm = 1/sqrt(K*1 + 1e-20)) and is anchored
  * on the reference's call site only.  exp/log are include/pnp_math.h's fixed fmaf sequences (Eigen's
  * vectorised exp is not reproducible anyway) so the HIP path can be compared bit-for-bit.
- * Known open point of the restatement (from the published sources as remembered; not checkable in this container): densecrf's
- * Permutohedral::compute has a scalar path, followed here (the blur is `old + 0.5 * (n1 + n2)` with a double literal, i.e. one
- * rounding to float per axis), and an SSE path with the same structure in float32 throughout (`0.5f * (n1 + n2)` rounded before
- * the add: two roundings), taken for more than two channels in SSE builds.  The two differ in last bits per axis pass; which one
- * a given pydensecrf build runs is part of what tests/golden/make_crf_golden.py pins when the package is available.
+ * Closed point (was open until round 3): densecrf's Permutohedral::compute has a scalar path, followed here (the blur is
+ * `old + 0.5 * (n1 + n2)` with a double literal), and an SSE path with the same structure in float32 (`0.5f * (n1 + n2)`).
+ * They cannot differ: (n1 + n2) is float + float and is rounded to float in both forms, 0.5 * x is exact, and old + t is exact
+ * in double, so its single rounding to float IS the float addition -- tests/test_oracle_golden.py asserts bit-identical marginals
+ * for the two forms.  The same test bounds what a different exp / log (libm here; torch / numpy / Eigen in the reference's
+ * stack) does to the labels: 0 flips on 158 016 pixels, |dQ| <= 1.8e-3.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off).
  */
@@ -26,6 +27,15 @@
 #include <math.h>
 
 #include "../include/pnp_math.h"
+
+/* Sensitivity variants, for tests/test_oracle_golden.py only (pnp_oracle_densecrf_variant): what the arithmetic this file
+ * FIXES BY DEFINITION could be in the reference's own stack, so that the label flips it can cause are measured, not guessed.
+ *   bit 0: libm expf / logf in place of include/pnp_math.h (torch's softmax, numpy's log and Eigen's exp each use their own)
+ *   bit 1: float32 lattice blur `old + 0.5f * (n1 + n2)` (densecrf's SSE path) in place of the scalar path (provably identical)
+ * 0 = the oracle the HIP path is compared with. */
+static int g_variant = 0;
+static float oracle_expf(float x) { return (g_variant & 1) ? expf(x) : pnp_expf(x); }
+static float oracle_logf(float x) { return (g_variant & 1) ? logf(x) : pnp_logf(x); }
 
 typedef struct {
     int d, N, M;
@@ -220,7 +230,15 @@ static void lattice_compute(const lattice_t *L, float *out, const float *in, int
             int b = L->n2[(size_t)j * M + i] + 1;
             float *n1_val = values + (size_t)a * vs;
             float *n2_val = values + (size_t)b * vs;
-            for (int k = 0; k < vs; k++) new_val[k] = (float)(old_val[k] + 0.5 * (n1_val[k] + n2_val[k]));
+            if (g_variant & 2) {
+                for (int k = 0; k < vs; k++) {
+                    float t = n1_val[k] + n2_val[k];
+                    t = 0.5f * t;
+                    new_val[k] = old_val[k] + t;
+                }
+            } else {
+                for (int k = 0; k < vs; k++) new_val[k] = (float)(old_val[k] + 0.5 * (n1_val[k] + n2_val[k]));
+            }
         }
         float *t = values;
         values = new_values;
@@ -256,7 +274,7 @@ static void exp_and_normalize(float *Q, const float *in, int K, int N) {
             if (b[k] > m || b[k] != b[k]) m = b[k];
         float s = 0;
         for (int k = 0; k < K; k++) {
-            float e = pnp_expf(b[k] - m);
+            float e = oracle_expf(b[k] - m);
             Q[(size_t)i * K + k] = e;
             s += e;
         }
@@ -273,15 +291,8 @@ static void pairwise_apply(const lattice_t *L, const float *norm, float w, float
         for (int k = 0; k < K; k++) out[(size_t)i * K + k] = -w * (out[(size_t)i * K + k] * norm[i]);
 }
 
-/* maps: (K,H,W) blurred score maps; rgb: (H,W,3) uint8.
- * q_out (optional): (K,H,W) marginals; map_out: (H,W) float32 argmax labels;
- * stats_out (optional): [M_gauss, M_bilateral]. */
-int pnp_oracle_densecrf(const float *maps, const uint8_t *rgb, int K, int H, int W, int iters,
-                        float pos_w, float pos_xy, float bi_w, float bi_xy, float bi_rgb,
-                        float *q_out, float *map_out, int *stats_out) {
-    int N = H * W;
-    float *unary = (float *)malloc(sizeof(float) * (size_t)N * K);
-    /* F.softmax(dim=0) then unary_from_softmax: -log(clip(p, 1e-5, 1)) */
+/* F.softmax(dim=0) then unary_from_softmax: -log(clip(p, 1e-5, 1)); maps (K,N) channel-major -> unary (N,K) pixel-major */
+static void unary_stage(const float *maps, int K, int N, float *unary) {
     for (int i = 0; i < N; i++) {
         float m = maps[i];
         for (int k = 1; k < K; k++) {
@@ -291,15 +302,42 @@ int pnp_oracle_densecrf(const float *maps, const uint8_t *rgb, int K, int H, int
         float s = 0;
         float e[1024];
         for (int k = 0; k < K; k++) {
-            e[k] = pnp_expf(maps[(size_t)k * N + i] - m);
+            e[k] = oracle_expf(maps[(size_t)k * N + i] - m);
             s += e[k];
         }
         for (int k = 0; k < K; k++) {
             float p = e[k] / s;
             if (p < 1e-5f) p = 1e-5f;
             else if (p > 1.0f) p = 1.0f;
-            unary[(size_t)i * K + k] = -pnp_logf(p);
+            unary[(size_t)i * K + k] = -oracle_logf(p);
         }
+    }
+}
+
+/* the unary stage alone, (K,N) in -> (K,N) out (tests: against torch F.softmax + numpy -log(clip)) */
+int pnp_oracle_unary(const float *maps, int K, int N, float *unary_kn) {
+    float *u = (float *)malloc(sizeof(float) * (size_t)N * K);
+    g_variant = 0;
+    unary_stage(maps, K, N, u);
+    for (int i = 0; i < N; i++)
+        for (int k = 0; k < K; k++) unary_kn[(size_t)k * N + i] = u[(size_t)i * K + k];
+    free(u);
+    return 0;
+}
+
+/* maps: (K,H,W) blurred score maps; rgb: (H,W,3) uint8.
+ * q_out (optional): (K,H,W) marginals; map_out: (H,W) float32 argmax labels;
+ * stats_out (optional): [M_gauss, M_bilateral]; unary_kn (optional): (K,N) unary energies to use instead of the unary stage. */
+static int densecrf_impl(const float *maps, const uint8_t *rgb, int K, int H, int W, int iters,
+                         float pos_w, float pos_xy, float bi_w, float bi_xy, float bi_rgb,
+                         float *q_out, float *map_out, int *stats_out, const float *unary_kn) {
+    int N = H * W;
+    float *unary = (float *)malloc(sizeof(float) * (size_t)N * K);
+    if (unary_kn) {
+        for (int i = 0; i < N; i++)
+            for (int k = 0; k < K; k++) unary[(size_t)i * K + k] = unary_kn[(size_t)k * N + i];
+    } else {
+        unary_stage(maps, K, N, unary);
     }
     float *fg = (float *)malloc(sizeof(float) * (size_t)N * 2);
     float *fb = (float *)malloc(sizeof(float) * (size_t)N * 5);
@@ -358,4 +396,21 @@ int pnp_oracle_densecrf(const float *maps, const uint8_t *rgb, int K, int H, int
     lattice_free(&Lg);
     lattice_free(&Lb);
     return 0;
+}
+
+int pnp_oracle_densecrf(const float *maps, const uint8_t *rgb, int K, int H, int W, int iters,
+                        float pos_w, float pos_xy, float bi_w, float bi_xy, float bi_rgb,
+                        float *q_out, float *map_out, int *stats_out) {
+    g_variant = 0;
+    return densecrf_impl(maps, rgb, K, H, W, iters, pos_w, pos_xy, bi_w, bi_xy, bi_rgb, q_out, map_out, stats_out, NULL);
+}
+
+/* the same mean-field under a sensitivity variant (see g_variant) and / or with externally computed unary energies */
+int pnp_oracle_densecrf_variant(const float *maps, const uint8_t *rgb, int K, int H, int W, int iters,
+                                float pos_w, float pos_xy, float bi_w, float bi_xy, float bi_rgb,
+                                float *q_out, float *map_out, int variant, const float *unary_kn) {
+    g_variant = variant;
+    int r = densecrf_impl(maps, rgb, K, H, W, iters, pos_w, pos_xy, bi_w, bi_xy, bi_rgb, q_out, map_out, NULL, unary_kn);
+    g_variant = 0;
+    return r;
 }

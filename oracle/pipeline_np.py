@@ -351,6 +351,38 @@ def densecrf(rgb, maps, want_q=False, **kw):
     return out
 
 
+def densecrf_variant(rgb, maps, variant=0, unary=None, **kw):
+    """The same mean-field with the arithmetic the oracle fixes by definition swapped for what the reference's own stack may
+    use (variant bit 0: libm exp / log; bit 1: float32 two-rounding lattice blur) and / or with externally computed unary
+    energies (K,H,W) -- sensitivity tests only (tests/test_oracle_golden.py).  Returns (labels, marginals)."""
+    p = dict(CRF_PARAMS)
+    p.update(kw)
+    K, H, W = maps.shape
+    maps = np.ascontiguousarray(maps, dtype=F32)
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    out = np.empty((H, W), dtype=F32)
+    q = np.empty((K, H, W), dtype=F32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    u = np.ascontiguousarray(unary, dtype=F32) if unary is not None else None
+    fn = _lib().pnp_oracle_densecrf_variant
+    fn.restype = ctypes.c_int
+    fn(maps.ctypes.data_as(fp), rgb.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ctypes.c_int(K), ctypes.c_int(H),
+       ctypes.c_int(W), ctypes.c_int(p["iters"]), ctypes.c_float(p["pos_w"]), ctypes.c_float(p["pos_xy"]), ctypes.c_float(p["bi_w"]),
+       ctypes.c_float(p["bi_xy"]), ctypes.c_float(p["bi_rgb"]), q.ctypes.data_as(fp), out.ctypes.data_as(fp), ctypes.c_int(variant),
+       u.ctypes.data_as(fp) if u is not None else None)
+    return out, q
+
+
+def crf_unary(maps):
+    """The oracle's unary stage alone: softmax over channels, -log(clip(p, 1e-5, 1)) with include/pnp_math.h's exp / log."""
+    K, H, W = maps.shape
+    maps = np.ascontiguousarray(maps, dtype=F32)
+    out = np.empty((K, H, W), dtype=F32)
+    fp = ctypes.POINTER(ctypes.c_float)
+    _lib().pnp_oracle_unary(maps.ctypes.data_as(fp), ctypes.c_int(K), ctypes.c_int(H * W), out.ctypes.data_as(fp))
+    return out
+
+
 def postprocess(mode, maps, rgb, hw):
     """PnP.py:1002-1028.  mode: 'blur+crf' | 'crf' | 'blur' | None."""
     if mode is None:

@@ -26,7 +26,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from pnp_ovss import host, synth  # noqa: E402
-from pnp_ovss.datasets import make_dataset, prefetch  # noqa: E402
+from pnp_ovss.datasets import make_dataset, prefetch, wait_ready  # noqa: E402
 from pnp_ovss.model import Segmenter  # noqa: E402
 
 
@@ -125,6 +125,13 @@ def main(rank, world_size, args):
                                        threshold=args.threshold, postprocess=args.postprocess,
                                        max_pixels_per_image=ds.max_pixels, max_channels=ds.max_channels,
                                        crf_chunk=args.crf_chunk, class_ids=ds.class_ids)))
+    if args.pipelines > 1 and rank == 0:
+        free_b, total_b = torch.cuda.mem_get_info()
+        used = [m.engine.allocated_bytes() for m, _ in replicas]
+        print(f"--pipelines {args.pipelines}: {sum(used) / 2**30:.1f} GiB in {len(used)} replicas "
+              f"({max(used) / 2**30:.1f} GiB each: weights + workspace), {free_b / 2**30:.1f} GiB of {total_b / 2**30:.0f} GiB free", flush=True)
+        if free_b < 0.05 * total_b:
+            print("warning: less than 5 % of device memory free: lower --pipelines or --batch_size", flush=True)
     n_img = 0
     t_loop = time.perf_counter()
     # Two batches in flight: the host half of batch i+1 (class lookup, tokenisation, merge plans, uploads) and the
@@ -162,9 +169,12 @@ def main(rank, world_size, args):
                 with torch.cuda.stream(torch.cuda.Stream()):
                     while True:
                         with lock:
+                            if errors:                        # another replica failed: stop taking batches
+                                return
                             bi, batch = next(it, (None, None))
                             if batch is None or (args.max_batches and bi >= args.max_batches):
                                 return
+                        wait_ready(batch)                     # produced on the prefetch thread's stream, consumed on this one
                         best, caps = [], []
                         for img_id in batch["img_ids"]:
                             b, names, cap = ds.predicted_classes(img_id)
@@ -202,6 +212,7 @@ def main(rank, world_size, args):
             b, names, cap = ds.predicted_classes(img_id)
             best.append(b)
             caps.append(cap)
+        wait_ready(batch)
         prep = seg.prepare(caps, best, batch["org_images"], batch["label_trues"], batch.get("gt_dev"))
         for layer, head in pairs:
             pargs = argparse.Namespace(**{**vars(args), "max_att_block_num": layer, "prune_att_head": str(head)})

@@ -134,6 +134,7 @@ struct pnp_engine {
         bool maps_in_2 = false;   // where the current maps live after blur
     } post;
 
+    GemmProfile* gemm_prof = nullptr;          // live timing ring of this engine's dense GEMM launches (allocated on first enable)
     // live timing of one pipeline stage (bench.py's hbm roofline record for the DenseCRF mean-field): event pairs
     // on the launch stream around the stage, algorithmic bytes summed beside them
     struct StageProfile {
@@ -229,6 +230,22 @@ GemmArgs G_(const void* A, int lda, const void* B, int ldb, int M, int N, int K)
     return g;
 }
 
+// every GEMM of an engine goes through here: the launch is timed into the engine's own ring when profiling is on
+int egemm(pnp_engine* e, int bf, GemmArgs g, hipStream_t s) {
+    g.prof = e->gemm_prof;
+    return gemm_nt(bf, g, s);
+}
+
+// a text-side Linear (M = B*L rows): in the split-bf16 mode the weight is a (hi | lo) bf16 pair and the fp32 activations are
+// split by the kernel (gemm_nt_small_x3_kernel); otherwise the compute type's generic kernel
+int tgemm(pnp_engine* e, GemmArgs g, hipStream_t s) {
+    if (e->x3) {
+        g.a_f32 = 1;
+        g.B_lo = (const char*)g.B + (size_t)g.N * g.K * 2;      // make_weight(split): lo array behind the hi array
+    }
+    return egemm(e, e->bf, g, s);
+}
+
 const char* kVitNames[] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight",
                            "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
                            "mlp.fc2.weight", "mlp.fc2.bias"};
@@ -260,6 +277,13 @@ extern "C" void pnp_destroy(pnp_engine* e) {
     (void)hipDeviceSynchronize();
     for (void* p : e->allocs) (void)hipFree(p);
     for (auto& b : e->staging) if (b.p) (void)hipFree(b.p);
+    if (e->gemm_prof) {
+        for (int i = 0; i < e->gemm_prof->created; i++) {
+            (void)hipEventDestroy(e->gemm_prof->ev0[i]);
+            (void)hipEventDestroy(e->gemm_prof->ev1[i]);
+        }
+        delete e->gemm_prof;
+    }
     for (hipEvent_t ev : e->crf_prof.ev0) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->crf_prof.ev1) (void)hipEventDestroy(ev);
     delete e;
@@ -571,15 +595,15 @@ extern "C" int pnp_finalize_weights(pnp_engine* e) {
         HIPCHK(e, hipMemcpy(fused, wq, (size_t)H * H * 4, hipMemcpyDeviceToDevice));
         HIPCHK(e, hipMemcpy(fused + (size_t)H * H, wk, (size_t)H * H * 4, hipMemcpyDeviceToDevice));
         HIPCHK(e, hipMemcpy(fused + (size_t)2 * H * H, wv, (size_t)H * H * 4, hipMemcpyDeviceToDevice));
-        int r = make_weight(e, fused, 3 * H, H, false, &t.qkv_w);
-        if (r == PNP_OK && i > e->SL) r = make_weight(e, fused, 3 * H, H, true, &t.qkv_wT);
+        int r = make_weight(e, fused, 3 * H, H, false, &t.qkv_w, e->x3);
+        if (r == PNP_OK && i > e->SL) r = make_weight(e, fused, 3 * H, H, true, &t.qkv_wT, e->x3);
         (void)hipFree(fused);
         if (r != PNP_OK) return r;
-        KCHK(e, make_weight(e, wso, H, H, false, &t.so_w));
-        KCHK(e, make_weight(e, wcq, H, H, false, &t.cq_w));
-        KCHK(e, make_weight(e, wco, H, H, false, &t.co_w));
-        KCHK(e, make_weight(e, wi, I, H, false, &t.i_w));
-        KCHK(e, make_weight(e, wo, H, I, false, &t.o_w));
+        KCHK(e, make_weight(e, wso, H, H, false, &t.so_w, e->x3));
+        KCHK(e, make_weight(e, wcq, H, H, false, &t.cq_w, e->x3));
+        KCHK(e, make_weight(e, wco, H, H, false, &t.co_w, e->x3));
+        KCHK(e, make_weight(e, wi, I, H, false, &t.i_w, e->x3));
+        KCHK(e, make_weight(e, wo, H, I, false, &t.o_w, e->x3));
         if (e->x3) {               // (hi | lo) halves over all layers: hi[TL*H*D] then lo[TL*H*D]
             const size_t half = (size_t)TL * H * D * 2, off = (size_t)i * H * D * 2;
             KCHK(e, split_f32(wck, (char*)e->ck_w + off, (char*)e->ck_w + half + off, (size_t)H * D, 0));
@@ -589,13 +613,13 @@ extern "C" int pnp_finalize_weights(pnp_engine* e) {
             KCHK(e, cast_f32(e->bf, wcv, (char*)e->cv_w + (size_t)i * H * D * e->esz, (size_t)H * D, 0));
         }
         if (i >= e->SL) {
-            KCHK(e, make_weight(e, wo, H, I, true, &t.o_wT));      // [I][H]
-            KCHK(e, make_weight(e, wi, I, H, true, &t.i_wT));      // [H][I]
-            KCHK(e, make_weight(e, wco, H, H, true, &t.co_wT));
+            KCHK(e, make_weight(e, wo, H, I, true, &t.o_wT, e->x3));      // [I][H]
+            KCHK(e, make_weight(e, wi, I, H, true, &t.i_wT, e->x3));      // [H][I]
+            KCHK(e, make_weight(e, wco, H, H, true, &t.co_wT, e->x3));
         }
         if (i > e->SL) {
-            KCHK(e, make_weight(e, wcq, H, H, true, &t.cq_wT));
-            KCHK(e, make_weight(e, wso, H, H, true, &t.so_wT));
+            KCHK(e, make_weight(e, wcq, H, H, true, &t.cq_wT, e->x3));
+            KCHK(e, make_weight(e, wso, H, H, true, &t.so_wT, e->x3));
         }
     }
 #undef NEED
@@ -624,7 +648,7 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
     {
         GemmArgs g = G_(e->patches, 768, e->patch_w, 768, B * e->PP, D, 768);
         g.bias = e->patch_b; g.resid = e->pos; g.ldr = D; g.out_f32 = e->x; g.ldo = D; g.row_div = e->PP;
-        KCHK(e, gemm_nt(bf, g, s));
+        KCHK(e, egemm(e, bf, g, s));
     }
     const float scale = 1.0f / sqrtf(64.f);
     if (e->x3) {
@@ -644,27 +668,27 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
                 GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 3 * D, D);
                 g.A_lo = xn_lo; g.B_lo = qkv_lo;
                 g.bias = w.qkv_b; g.out_t = e->qk; g.out_lo = qk_lo; g.ldo_t = 3 * D;
-                KCHK(e, gemm_nt(1, g, s));
+                KCHK(e, egemm(e, 1, g, s));
             }
             KCHK(e, vit_attention_x3(e->qk, qk_lo, 3 * D, D, e->ctx, ctx_lo, B, e->c.vit_heads, N, scale, s));
             {
                 GemmArgs g = G_(e->ctx, D, w.proj_w, D, M, D, D);
                 g.A_lo = ctx_lo; g.B_lo = (const char*)w.proj_w + (size_t)D * D * 2;
                 g.bias = w.proj_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
-                KCHK(e, gemm_nt(1, g, s));
+                KCHK(e, egemm(e, 1, g, s));
             }
             KCHK(e, layernorm(1, e->x, w.n2w, w.n2b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s, xn_lo));
             {
                 GemmArgs g = G_(e->xn, D, w.fc1_w, D, M, F, D);
                 g.A_lo = xn_lo; g.B_lo = (const char*)w.fc1_w + (size_t)F * D * 2;
                 g.bias = w.fc1_b; g.mode = GEMM_EPI_GELU; g.out_t = e->h1; g.out_lo = h1_lo; g.ldo_t = F;
-                KCHK(e, gemm_nt(1, g, s));
+                KCHK(e, egemm(e, 1, g, s));
             }
             {
                 GemmArgs g = G_(e->h1, F, w.fc2_w, F, M, D, F);
                 g.A_lo = h1_lo; g.B_lo = (const char*)w.fc2_w + (size_t)D * F * 2;
                 g.bias = w.fc2_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
-                KCHK(e, gemm_nt(1, g, s));
+                KCHK(e, egemm(e, 1, g, s));
             }
         }
         KCHK(e, layernorm(1, e->x, e->vnorm_w, e->vnorm_b, e->c.vit_ln_eps, M, D, e->emb32, e->embT, nullptr, nullptr, s,
@@ -677,37 +701,37 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
         if (bf) {   // q | k | v natural in one launch: [M, 3D]; the attention kernel transposes V on its LDS reads
             GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 3 * D, D);
             g.bias = w.qkv_b; g.out_t = e->qk; g.ldo_t = 3 * D;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, egemm(e, bf, g, s));
             KCHK(e, vit_attention(bf, e->qk, 3 * D, D, (const char*)e->qk + (size_t)2 * D * e->esz, 3 * D, e->Npad, e->ctx, B,
                                   e->c.vit_heads, N, scale, s));
         } else {
         {   // q | k  natural: [M, 2D]
             GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 2 * D, D);
             g.bias = w.qkv_b; g.out_t = e->qk; g.ldo_t = 2 * D;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, egemm(e, bf, g, s));
         }
         {   // V^T: [D, B*Npad] = Wv . xn^T, token columns padded per image
             GemmArgs g = G_((const char*)w.qkv_w + (size_t)2 * D * D * e->esz, D, e->xn, D, D, M, D);
             g.bias = w.qkv_b + 2 * D; g.bias_on_rows = 1; g.out_t = e->vt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, egemm(e, bf, g, s));
         }
         KCHK(e, vit_attention(bf, e->qk, 2 * D, D, e->vt, ldv, e->Npad, e->ctx, B, e->c.vit_heads, N, scale, s));
         }
         {
             GemmArgs g = G_(e->ctx, D, w.proj_w, D, M, D, D);
             g.bias = w.proj_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, egemm(e, bf, g, s));
         }
         KCHK(e, layernorm(bf, e->x, w.n2w, w.n2b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s));
         {
             GemmArgs g = G_(e->xn, D, w.fc1_w, D, M, F, D);
             g.bias = w.fc1_b; g.mode = GEMM_EPI_GELU; g.out_t = e->h1; g.ldo_t = F;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, egemm(e, bf, g, s));
         }
         {
             GemmArgs g = G_(e->h1, F, w.fc2_w, F, M, D, F);
             g.bias = w.fc2_b; g.resid = e->x; g.ldr = D; g.out_f32 = e->x; g.ldo = D;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, egemm(e, bf, g, s));
         }
     }
     KCHK(e, layernorm(bf, e->x, e->vnorm_w, e->vnorm_b, e->c.vit_ln_eps, M, D, e->emb32, e->embT, nullptr, nullptr, s));
@@ -733,13 +757,13 @@ extern "C" int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream) {
             GemmArgs g = G_(e->embT, D, ck, D, M, TL * H, D);
             g.A_lo = emb_lo; g.B_lo = ck + whalf;
             g.bias = e->ck_b; g.out_f32 = (float*)e->Knat; g.ldo = TL * H;
-            KCHK(e, gemm_nt(1, g, s));
+            KCHK(e, egemm(e, 1, g, s));
         }
         {
             GemmArgs g = G_(cv, D, e->embT, D, TL * H, M, D);
             g.A_lo = cv + whalf; g.B_lo = emb_lo;
             g.bias = e->cv_b; g.bias_on_rows = 1; g.out_f32 = (float*)e->Vt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
-            KCHK(e, gemm_nt(1, g, s));
+            KCHK(e, egemm(e, 1, g, s));
         }
         {
             const int nVn = TL - SL;
@@ -747,7 +771,7 @@ extern "C" int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream) {
             GemmArgs g = G_(e->embT, D, cv + off, D, M, nVn * H, D);
             g.A_lo = emb_lo; g.B_lo = cv + whalf + off;
             g.bias = e->cv_b + (size_t)SL * H; g.out_f32 = (float*)e->Vnat; g.ldo = nVn * H;
-            KCHK(e, gemm_nt(1, g, s));
+            KCHK(e, egemm(e, 1, g, s));
         }
         if (TL - SL - 1 > 0) {
             const int nKt = TL - SL - 1;
@@ -755,31 +779,31 @@ extern "C" int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream) {
             GemmArgs g = G_(ck + off, D, e->embT, D, nKt * H, M, D);
             g.A_lo = ck + whalf + off; g.B_lo = emb_lo;
             g.bias = e->ck_b + (size_t)(SL + 1) * H; g.bias_on_rows = 1; g.out_f32 = (float*)e->Kt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
-            KCHK(e, gemm_nt(1, g, s));
+            KCHK(e, egemm(e, 1, g, s));
         }
         return PNP_OK;
     }
     {
         GemmArgs g = G_(e->embT, D, e->ck_w, D, M, TL * H, D);
         g.bias = e->ck_b; g.out_t = e->Knat; g.ldo_t = TL * H;
-        KCHK(e, gemm_nt(bf, g, s));
+        KCHK(e, egemm(e, bf, g, s));
     }
     {
         GemmArgs g = G_(e->cv_w, D, e->embT, D, TL * H, M, D);
         g.bias = e->cv_b; g.bias_on_rows = 1; g.out_t = e->Vt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
-        KCHK(e, gemm_nt(bf, g, s));
+        KCHK(e, egemm(e, bf, g, s));
     }
     {
         const int nVn = TL - SL;
         GemmArgs g = G_(e->embT, D, (const char*)e->cv_w + (size_t)SL * H * D * e->esz, D, M, nVn * H, D);
         g.bias = e->cv_b + (size_t)SL * H; g.out_t = e->Vnat; g.ldo_t = nVn * H;
-        KCHK(e, gemm_nt(bf, g, s));
+        KCHK(e, egemm(e, bf, g, s));
     }
     if (TL - SL - 1 > 0) {
         const int nKt = TL - SL - 1;
         GemmArgs g = G_((const char*)e->ck_w + (size_t)(SL + 1) * H * D * e->esz, D, e->embT, D, nKt * H, M, D);
         g.bias = e->ck_b + (size_t)(SL + 1) * H; g.bias_on_rows = 1; g.out_t = e->Kt; g.ldo_t = ldv; g.col_div = N; g.col_pad = e->Npad;
-        KCHK(e, gemm_nt(bf, g, s));
+        KCHK(e, egemm(e, bf, g, s));
     }
     return PNP_OK;
 }
@@ -805,19 +829,19 @@ extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const
         {
             GemmArgs g = G_(hT, H, w.qkv_w, H, R, 3 * H, H);
             g.bias = w.qkv_b; g.out_t = a.qkv; g.ldo_t = 3 * H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, text_self_attn(bf, a.qkv, d_mask, ld, e->ctx_s, stash ? a.Ps : nullptr, B, L, H, s));
         {
             GemmArgs g = G_(e->ctx_s, H, w.so_w, H, R, H, H);
             g.bias = w.so_b; g.resid = h; g.ldr = H; g.out_f32 = e->tmp; g.ldo = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, layernorm(bf, e->tmp, w.sln_w, w.sln_b, e->c.txt_ln_eps, R, H, a.a_out, a.a_outT, a.a_hat, a.a_rstd, s));
         {
             GemmArgs g = G_(a.a_outT, H, w.cq_w, H, R, H, H);
             g.bias = w.cq_b; g.out_t = a.qc; g.ldo_t = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, xattn(bf, 0, (const char*)e->Knat + (size_t)i * H * e->esz, TL * H,
                       (const char*)e->Vt + (size_t)i * H * ldv * e->esz, ldv, e->Npad, a.qc, H, e->ctx_c, H,
@@ -825,18 +849,18 @@ extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const
         {
             GemmArgs g = G_(e->ctx_c, H, w.co_w, H, R, H, H);
             g.bias = w.co_b; g.resid = a.a_out; g.ldr = H; g.out_f32 = e->tmp; g.ldo = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, layernorm(bf, e->tmp, w.cln_w, w.cln_b, e->c.txt_ln_eps, R, H, a.c_out, a.c_outT, a.c_hat, a.c_rstd, s));
         {
             GemmArgs g = G_(a.c_outT, H, w.i_w, H, R, I, H);
             g.bias = w.i_b; g.mode = GEMM_EPI_GELU; g.aux = a.u; g.ld_aux = I; g.out_t = e->g; g.ldo_t = I;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         {
             GemmArgs g = G_(e->g, I, w.o_w, I, R, H, I);
             g.bias = w.o_b; g.resid = a.c_out; g.ldr = H; g.out_f32 = e->tmp; g.ldo = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, layernorm(bf, e->tmp, w.oln_w, w.oln_b, e->c.txt_ln_eps, R, H, a.h_out, a.h_outT, a.o_hat, a.o_rstd, s));
         h = a.h_out;
@@ -868,18 +892,18 @@ extern "C" int pnp_xattn_grad_layer(pnp_engine* e, int32_t B, int32_t L, int32_t
         {   // dg = (d_pre . Wo2) * gelu'(u)
             GemmArgs g = G_(e->d_preT, H, w.o_wT, H, R, I, H);
             g.mode = GEMM_EPI_GELU_GRAD; g.aux = a.u; g.ld_aux = I; g.out_t = e->dg; g.ldo_t = I;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         {   // dc = d_pre + dg . Wi
             GemmArgs g = G_(e->dg, I, w.i_wT, I, R, H, I);
             g.resid = e->d_pre; g.ldr = H; g.out_f32 = e->dc; g.ldo = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, layernorm_bwd(bf, e->dc, w.cln_w, a.c_hat, a.c_rstd, R, H, e->d_cpre, e->d_cpreT, s));
         {
             GemmArgs g = G_(e->d_cpreT, H, w.co_wT, H, R, H, H);
             g.out_t = e->dctxc; g.ldo_t = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         const char* vnat = (const char*)e->Vnat + (size_t)(i - SL) * H * e->esz;
         if (i == layer) {
@@ -891,19 +915,19 @@ extern "C" int pnp_xattn_grad_layer(pnp_engine* e, int32_t B, int32_t L, int32_t
         {
             GemmArgs g = G_(e->dqc, H, w.cq_wT, H, R, H, H);
             g.resid = e->d_cpre; g.ldr = H; g.out_f32 = e->da; g.ldo = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, layernorm_bwd(bf, e->da, w.sln_w, a.a_hat, a.a_rstd, R, H, e->d_apre, e->d_apreT, s));
         {
             GemmArgs g = G_(e->d_apreT, H, w.so_wT, H, R, H, H);
             g.out_f32 = e->dctx_s; g.ldo = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, text_self_attn_bwd(bf, a.qkv, e->dctx_s, a.Ps, e->dS, e->dqkv, B, L, H, s));
         {
             GemmArgs g = G_(e->dqkv, 3 * H, w.qkv_wT, 3 * H, R, H, 3 * H);
             g.resid = e->d_apre; g.ldr = H; g.out_f32 = e->dh; g.ldo = H;
-            KCHK(e, gemm_nt(bf, g, s));
+            KCHK(e, tgemm(e, g, s));
         }
     }
     return PNP_OK;
@@ -1433,7 +1457,14 @@ extern "C" size_t pnp_allocated_bytes(const pnp_engine* e) { return e ? e->alloc
 
 extern "C" int pnp_profile_enable(pnp_engine* e, int32_t on) {
     if (!e) return PNP_ERR_ARG;
-    GemmProfile& pf = gemm_profile();
+    if (!e->gemm_prof) {
+        if (!on) {
+            e->crf_prof.on = false;
+            return PNP_OK;
+        }
+        e->gemm_prof = new GemmProfile();
+    }
+    GemmProfile& pf = *e->gemm_prof;
     pf.on = on != 0;
     pf.period = on > 1 ? on : 1;
     pf.seq = 0;
@@ -1467,7 +1498,11 @@ extern "C" int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* lau
 
 extern "C" int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms) {
     if (!e || !launches || !flops || !ms) return PNP_ERR_ARG;
-    GemmProfile& pf = gemm_profile();
+    if (!e->gemm_prof) {
+        *launches = 0; *flops = 0; *ms = 0;
+        return PNP_OK;
+    }
+    GemmProfile& pf = *e->gemm_prof;
     double total = 0;
     for (int i = 0; i < pf.used; i++) {
         HIPCHK(e, hipEventSynchronize(pf.ev1[i]));

@@ -6,6 +6,8 @@ namespace pnp {
 
 enum { GEMM_EPI_LINEAR = 0, GEMM_EPI_GELU = 1, GEMM_EPI_GELU_GRAD = 2 };
 
+struct GemmProfile;
+
 struct GemmArgs {
     const void* A = nullptr;   // [M, lda] T
     const void* B = nullptr;   // [N, ldb] T
@@ -27,15 +29,19 @@ struct GemmArgs {
     const void* A_lo = nullptr;    // [M, lda] bf16
     const void* B_lo = nullptr;    // [N, ldb] bf16
     void* out_lo = nullptr;        // optional bf16 low part of a split output [*, ldo_t] (out_t holds the high part)
+    int a_f32 = 0;                 // 1: A is fp32 [M, lda] and is split by the kernel (text-side form: B = bf16 hi, B_lo = bf16 lo,
+                                   // outputs fp32 -- out_t, if given, is a float array like out_f32)
     int row_div = 0;               // >0: patch rows -> token rows b*(row_div+1)+1+p, resid = pos_embed
     int col_div = 0, col_pad = 0;  // >0: output column n -> (n / col_div) * col_pad + n % col_div
+    struct GemmProfile* prof = nullptr;     // live timing ring of the calling engine (bench.py roofline), null = none
     unsigned long long* stamps = nullptr;   // diagnostics (DEV builds, PNP_GEMM_STAMPS): per-workgroup clock stamps, 8 per block
     int ablate = 0;                // DEV builds only (PNP_GEMM_ABLATE): 1 = no steady-state DMA, 2 = no MFMA
 };
 
 int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s);
 
-// Optional live timing of the big-tile GEMM launches (bench.py roofline): a ring of event pairs.
+// Optional live timing of the big-tile GEMM launches (bench.py roofline): a ring of event pairs.  One per engine (engines
+// are driven from different host threads when several batches are in flight); gemm_nt touches it through GemmArgs::prof.
 struct GemmProfile {
     bool on = false;
     static constexpr int kMax = 8192;
@@ -46,7 +52,6 @@ struct GemmProfile {
     long long launches = 0;
     double flops = 0;
 };
-GemmProfile& gemm_profile();
 int gemm_read_stamps(unsigned long long* host_out, int max_blocks);
 
 }  // namespace pnp

@@ -1022,6 +1022,143 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
+// ------------------------------------------------------------------------------------------
+// Text-side GEMM of the split-bf16 mode: C[M,N] = A[M,K] . B[N,K]^T with A = fp32 activations (M = B*L rows, a few hundred
+// to a few thousand) and B = a weight stored as a bf16 (hi | lo) pair.  The fp32 MFMA runs at 1/16 of the bf16 rate, so the
+// exact-fp32 form of these launches is MFMA-bound at ~40 us each (1188 launches per bench step); here the activation tile is
+// split into (hi, lo) bf16 ONCE by the threads that stage it (global -> registers -> two 16-byte LDS stores per 8 values),
+// the weight tile arrives by LDS-DMA already split, and each fragment pair issues three v_mfma_f32_16x16x32_bf16
+// (a_hi.b_lo, a_lo.b_hi, a_hi.b_hi: fp32-class product, see the wide kernel's X3 note).
+// Tile 64 x 64, 4 waves of 32 x 32, 32-deep k-slabs, 3-slot ring: slot = A_hi | A_lo | B_hi | B_lo, each 64 rows x 64 bytes,
+// 16-byte chunks swizzled chunk ^= (-(row >> 2)) & 3 (the 16 lanes a ds_read_b128 services together -- 4 rows of one q
+// and 8 rows of the next -- then hit 16 different slots).  Epilogue: the generic store_frag (bias, residual, GELU + stash,
+// GELU', fp32 outputs), same accumulator layout as gemm_nt_big_kernel.
+__global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g) {
+    constexpr int BM = 64, BN = 64, NS = 3, ARR = 64 * 64, SLOT = 4 * ARR;
+    __shared__ __attribute__((aligned(16))) char smem[NS * SLOT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbn = g.N / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int nk = g.K / 32;
+
+    // A staging: thread -> row tid / 4, k elements 8 (tid % 4) .. + 7 of the slab (32 bytes of fp32)
+    const int a_row = tid >> 2, a_c = tid & 3;
+    int a_gr = m0 + a_row;
+    a_gr = a_gr < g.M ? a_gr : g.M - 1;
+    const float* a_src = reinterpret_cast<const float*>(g.A) + (size_t)a_gr * g.lda + a_c * 8;
+    const int a_dst = a_row * 64 + ((a_c ^ ((-(a_row >> 2)) & 3)) << 4);
+    // B DMA: wave w moves rows 16 w .. + 15 of B_hi and of B_lo (one 1 KB piece each per slab)
+    const char* Bh = reinterpret_cast<const char*>(g.B);
+    const char* Bl = reinterpret_cast<const char*>(g.B_lo);
+    uint32_t b_off;
+    {
+        const int row = wave * 16 + (lane >> 2);
+        int gr = n0 + row;
+        gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
+        const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
+        b_off = (uint32_t)gr * (uint32_t)g.ldb * 2 + c * 16;
+    }
+    auto issue_b = [&](int kt) {
+        char* st = smem + (kt % NS) * SLOT + 2 * ARR + wave * 1024;
+        const uint32_t koff = (uint32_t)kt * 64;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bh + (size_t)(b_off + koff)),
+                                         (__attribute__((address_space(3))) void*)st, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bl + (size_t)(b_off + koff)),
+                                         (__attribute__((address_space(3))) void*)(st + ARR), 16, 0, 0);
+    };
+    f32x4 ra0, ra1;                                   // the staged A values of the slab after next
+    auto load_a = [&](int kt) {
+        ra0 = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32);
+        ra1 = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32 + 4);
+    };
+    auto store_a = [&](int kt) {                      // x = hi + lo, both bf16 (round to nearest even)
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            h[e] = (bf16)ra0[e];
+            l[e] = (bf16)(ra0[e] - (float)h[e]);
+            h[4 + e] = (bf16)ra1[e];
+            l[4 + e] = (bf16)(ra1[e] - (float)h[4 + e]);
+        }
+        char* st = smem + (kt % NS) * SLOT + a_dst;
+        *reinterpret_cast<bf16x8*>(st) = h;
+        *reinterpret_cast<bf16x8*>(st + ARR) = l;
+    };
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment offsets: row of the 16-row tile = r, k = 8 q .. 8 q + 7 -> logical chunk q
+    const int fsw = (q ^ ((-(r >> 2)) & 3)) << 4;
+    const int fa_off = (wm * 32 + r) * 64 + fsw, fb_off = 2 * ARR + (wn * 32 + r) * 64 + fsw;
+
+    // prologue: slab 0 (A written at once), slab 1 (A in registers, B in flight)
+    load_a(0);
+    issue_b(0);
+    store_a(0);
+    if (nk > 1) {
+        load_a(1);
+        issue_b(1);
+    }
+    for (int kt = 0; kt < nk; kt++) {
+        // slab kt complete for everybody: own B pieces of slab kt landed (at most slab kt+1's two pieces still in flight;
+        // the A loads in front of them are then done too), own A stores of slab kt done
+        if (kt + 1 < nk) PNP_WAIT_VM_LGKM(2);
+        else PNP_WAIT_VM_LGKM(0);
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) store_a(kt + 1);             // slot (kt+1) % 3 was last read in iteration kt-2
+        if (kt + 2 < nk) {
+            load_a(kt + 2);
+            issue_b(kt + 2);                          // slot (kt+2) % 3 was last read in iteration kt-1: free since this barrier
+        }
+        const char* st = smem + (kt % NS) * SLOT;
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            ah[j] = *reinterpret_cast<const bf16x8*>(st + fa_off + j * 16 * 64);
+            al[j] = *reinterpret_cast<const bf16x8*>(st + ARR + fa_off + j * 16 * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            bh[i] = *reinterpret_cast<const bf16x8*>(st + fb_off + i * 16 * 64);
+            bl[i] = *reinterpret_cast<const bf16x8*>(st + ARR + fb_off + i * 16 * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[i], ah[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int m = m0 + wm * 32 + j * 16 + r;
+        if (m >= g.M) continue;
+        const RowCtx rc = row_ctx(g, m);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int n = n0 + wn * 32 + i * 16 + q * 4;
+            if (n >= g.Nvalid) continue;
+            store_frag<float>(g, rc, acc[i][j], m, n);
+        }
+    }
+}
+
+static int launch_small_x3(const GemmArgs& g, hipStream_t s) {
+    const int nbm = (g.M + 63) / 64, nbn = g.N / 64;
+    hipLaunchKernelGGL(gemm_nt_small_x3_kernel, dim3(nbm * nbn), dim3(256), 0, s, g);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs g) {
     constexpr int ROWB = 128;                       // bytes of k per LDS row per stage
@@ -1176,6 +1313,15 @@ static int dev_env(const char* name, int dflt) {
 // Host entry.  N is rounded up to the tile internally (loads clamp, stores mask on Nvalid).
 int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return PNP_ERR_ARG;
+    if (g.a_f32) {
+        // split-bf16 with fp32 activations (text side): A is split by the kernel, B is a (hi, lo) bf16 pair; fp32 epilogues
+        if (!g.B_lo || g.A_lo || g.K % 32 || (g.lda * 4) % 16 || (g.ldb * 2) % 16 || g.row_div || g.col_div || g.bias_on_rows ||
+            (g.N & 3))
+            return PNP_ERR_ARG;
+        g.Nvalid = g.N;
+        g.N = (g.N + 63) / 64 * 64;
+        return launch_small_x3(g, s);
+    }
     const bool x3 = g.A_lo || g.B_lo;                      // split-bf16 operands (bf16 pairs), fp32-facing epilogues
     if (x3) dtype_bf16 = 1;
     const int bk = dtype_bf16 ? 64 : 32;
@@ -1206,7 +1352,8 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
 #endif
         return dtype_bf16 ? launch_big<bf16, 64, 64, 32, 32, 3>(g, s) : launch_big<float, 64, 64, 32, 32, 3>(g, s);
     }
-    GemmProfile& pf = gemm_profile();
+    static GemmProfile never_on;                           // launches outside an engine (pnp_op_*) are not timed
+    GemmProfile& pf = g.prof ? *g.prof : never_on;
     // every `period`-th launch of the family is bracketed (1 = all of them: ~2.5 us of stream serialisation per launch)
     const bool timed = pf.on && pf.used < GemmProfile::kMax && (pf.seq++ % pf.period) == 0;
     if (timed) {
@@ -1257,11 +1404,6 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
         pf.flops += fl;
     }
     return r;
-}
-
-GemmProfile& gemm_profile() {
-    static GemmProfile p;
-    return p;
 }
 
 }  // namespace pnp

@@ -71,19 +71,26 @@ class _Base:
         from .jpeg import UnsupportedJpeg
         items = [list(it) for it in items]
         good = []
+        def on_host(k, why):
+            from PIL import Image
+            warnings.warn(f"image {items[k][1]}: {why}: decoded on the host")
+            items[k][2] = np.asarray(Image.open(io.BytesIO(items[k][2])).convert("RGB"))
+
         for k in todo:
             try:
                 from . import jpeg as J
                 J.parse(items[k][2])
                 good.append(k)
             except UnsupportedJpeg as exc:
-                from PIL import Image
-                warnings.warn(f"image {items[k][1]}: {exc}: decoded on the host")
-                items[k][2] = np.asarray(Image.open(io.BytesIO(items[k][2])).convert("RGB"))
+                on_host(k, exc)
         if good:
-            dec = hip.jpeg_decode_batch([items[k][2] for k in good])
-            for k, t in zip(good, dec):
-                items[k][2] = t
+            try:
+                dec = hip.jpeg_decode_batch([items[k][2] for k in good])
+                for k, t in zip(good, dec):
+                    items[k][2] = t
+            except RuntimeError as exc:          # a corrupt entropy stream fails the whole device batch: file by file on the host
+                for k in good:
+                    on_host(k, f"device decode of the batch failed ({exc})")
         if any(isinstance(it[2], np.ndarray) for it in items) and any(isinstance(it[2], torch.Tensor) for it in items):
             for it in items:                                       # mixed batch: everything onto the device
                 if isinstance(it[2], np.ndarray):
@@ -120,7 +127,20 @@ class _Base:
                 # the concatenated ground truth goes up here (this generator usually runs in the prefetch thread), not on
                 # the driver's critical path between the drop loop and the post-processing
                 batch["gt_dev"] = torch.from_numpy(np.concatenate([np.asarray(it[3], dtype=np.float32).reshape(-1) for it in items])).cuda()
+            if torch.cuda.is_available():
+                # the device tensors above (decoded RGB, resized + normalised images, ground truth) were produced on THIS
+                # thread's current stream; a consumer that works on another stream (CLI --pipelines workers) must order
+                # itself behind this event before it touches them (wait_ready)
+                batch["ready"] = torch.cuda.Event()
+                batch["ready"].record()
             yield batch
+
+
+def wait_ready(batch):
+    """Order the caller's current stream behind the producer of `batch` (see batches): no host synchronisation."""
+    ev = batch.get("ready")
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
 
 
 def _read_rgb(path, device_jpeg):

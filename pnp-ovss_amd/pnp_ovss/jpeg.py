@@ -43,11 +43,24 @@ def _u16(b, p):
 
 def parse(data: bytes):
     """Marker walk of one file -> dict(H, W, comps[{h, v, tq, td, ta}], qt{id: int32[64] natural order},
-    ht{(class, id): (counts[16], symbols)}, dri, scan_start, scan_end)."""
+    ht{(class, id): (counts[16], symbols)}, dri, scan_start, scan_end).  Anything the device decoder does not cover --
+    including truncated / malformed marker segments and 3-component files that are NOT YCbCr (Adobe APP14 transform 0,
+    or component ids 'R','G','B': libjpeg would not colour-convert them) -- raises UnsupportedJpeg, so the caller falls
+    back to Pillow instead of failing or silently converting the wrong colour space."""
+    try:
+        return _parse(data)
+    except UnsupportedJpeg:
+        raise
+    except (IndexError, ValueError, KeyError) as exc:
+        raise UnsupportedJpeg(f"malformed marker segment ({type(exc).__name__}: {exc})") from None
+
+
+def _parse(data: bytes):
     if len(data) < 4 or data[0] != 0xFF or data[1] != 0xD8:
         raise UnsupportedJpeg("not a JPEG stream")
     pos, n = 2, len(data)
     qt, ht, comps, H, W, dri = {}, {}, None, 0, 0, 0
+    adobe_transform = None
     while pos + 4 <= n:
         if data[pos] != 0xFF:
             raise UnsupportedJpeg("marker expected")
@@ -92,6 +105,8 @@ def parse(data: bytes):
                 p += 17 + ns
         elif m == 0xDD:
             dri = _u16(seg, 0)
+        elif m == 0xEE and len(seg) >= 12 and bytes(seg[:5]) == b"Adobe":
+            adobe_transform = seg[11]                  # 0: no colour transform (RGB / CMYK), 1: YCbCr, 2: YCCK
         elif m == 0xDA:
             if comps is None:
                 raise UnsupportedJpeg("scan before frame header")
@@ -108,6 +123,8 @@ def parse(data: bytes):
             if len(comps) == 1:
                 comps[0]["h"] = comps[0]["v"] = 1
             elif len(comps) == 3:
+                if adobe_transform == 0 or [c["id"] for c in comps] == [82, 71, 66]:
+                    raise UnsupportedJpeg("3-component file stored as RGB, not YCbCr (Adobe transform 0 / component ids R,G,B)")
                 c0 = comps[0]
                 if not (comps[1]["h"] == comps[2]["h"] == comps[1]["v"] == comps[2]["v"] == 1 and
                         (c0["h"], c0["v"]) in ((1, 1), (2, 1), (2, 2))):

@@ -441,8 +441,10 @@ class Segmenter:
         if self.coco and int(args.drop_iter) >= 3:
             run_1drop = False
         scale01 = (True, self.coco)                                 # Scale_0_1 on (1-drop, N-drop)
-        eng.post_prepare(prep["sizes"], prep["plans"], prep["luts"], prep["bgs"], rgb=prep["rgb"], gt=prep["gt"],
-                         want_crf=bool(self.mode and "crf" in self.mode))
+        if getattr(self, "_prepared", None) is not prep:            # once per batch: a (layer, head) sweep re-launches the same prep
+            eng.post_prepare(prep["sizes"], prep["plans"], prep["luts"], prep["bgs"], rgb=prep["rgb"], gt=prep["gt"],
+                             want_crf=bool(self.mode and "crf" in self.mode))
+            self._prepared = prep
         out1 = outn = None
         if run_1drop and agg is not None and self.mode == "blur+crf":
             # both branches share the image lattices: one DenseCRF run over two channel groups (same results)

@@ -9,6 +9,7 @@ Fixtures (inputs are regenerated from seeds by pnp_ovss.synth; only outputs are 
   gradcam_small.npz   compute_gradcam_ensemble, small geometry, B=2 ragged captions, all 12x12 maps
   gradcam_large.npz   compute_gradcam_ensemble, BLIP-ITM-large 336^2, B=1, L=25: map [7][9] + logits
   droploop_small.npz  Inference_BLIP_filteredcaption (drop_iter 4 and 1), picks per iteration
+  droploop_large.npz  the same at BLIP-ITM-large 336^2, B=2 ragged captions, drop_iter 4
   merge_tokens.npz    Mean_over_filtered_label_tokens on split / unsplit captions
   pipeline_voc.npz    save_img_union_attention end to end (blur / no post-process; CRF is not
   pipeline_psc.npz    importable here -> parity unpinned for CRF), hist .npy contents
@@ -93,8 +94,8 @@ def gen_gradcam_large():
     np.savez_compressed(os.path.join(HERE, "gradcam_large.npz"),
                         cfg=json.dumps(cfg.as_dict()), weight_seed=0, image_seed=1234, token_seed=1234,
                         n_classes=20, map_7_9=g[7][9].numpy(), map_7_0=g[7][0].numpy(),
-                        map_11_3=g[11][3].numpy(), logits=out.detach().numpy(),
-                        P7_h9=P7[:, 9], dP7_h9=dP7[:, 9])
+                        map_11_3=g[11][3].numpy(), map_9_3=g[9][3].numpy(), map_10_5=g[10][5].numpy(),
+                        logits=out.detach().numpy(), P7_h9=P7[:, 9], dP7_h9=dP7[:, 9])
     print("gradcam_large: map", g[7][9].shape, "max", g[7][9].max().item())
 
 
@@ -120,7 +121,8 @@ def gen_gradcam_large_768():
     g, _, out = itm.compute_gradcam_ensemble(args, m, torch.from_numpy(imgs), ["x"], tok500)
     np.savez_compressed(os.path.join(HERE, "gradcam_large_768.npz"), cfg=json.dumps(cfg.as_dict()), weight_seed=0,
                         image_seed=4321, token_seed=4321, n_classes=40, map_7_9=g[7][9].numpy().astype(np.float32),
-                        map_11_3=g[11][3].numpy().astype(np.float32), logits=out.detach().numpy())
+                        map_11_3=g[11][3].numpy().astype(np.float32), map_9_3=g[9][3].numpy().astype(np.float32),
+                        logits=out.detach().numpy())
     print("gradcam_large_768: map", g[7][9].shape, "max", g[7][9].max().item())
 
 
@@ -171,6 +173,51 @@ def gen_droploop_small():
                         weight_seed=4, image_seed=6, captions=np.array(caps),
                         input_ids=tok500.input_ids.numpy(), attention_mask=tok500.attention_mask.numpy(), **out)
     print("droploop_small:", {k: v.shape for k, v in out.items()})
+
+
+def gen_droploop_large():
+    """Inference_BLIP_filteredcaption (PnP.py:564-722) at FULL model size: BLIP-ITM-large 336^2, B = 2 with ragged captions
+    (20 and 12 classes: the shorter row carries [SEP] and zero pad rows inside the [3:-1] salience slice), drop_iter 4:
+    gradcam_0, gradcam_agg and the patches zeroed in front of every iteration (= the picks so far)."""
+    cfg = C.blip_itm_large(336)
+    m, itm, tok = _model(cfg, seed=0)
+    B, ncls = 2, [20, 12]
+    _, imgs = synth.synth_images(B, 336, seed=2024)
+    ids, mask = synth.synth_tokens(cfg, ncls, seed=2024)
+
+    class Fixed:                      # tokenizer stand-in returning the synthetic ids (one word-piece per class)
+        enc_token_id = cfg.enc_token_id
+        pad_token_id = 0
+
+        def __call__(self, caps, padding="longest", max_length=None, **kw):
+            from pnp_ovss.tokenizer import Encoding
+            L = max_length if padding == "max_length" else int(mask.sum(1).max())
+            return Encoding(torch.from_numpy(ids[:, :L].copy()), torch.from_numpy(mask[:, :L].copy()))
+
+        def decode(self, token_ids):                 # PnP.py:658 (word strings of the dead visualisation block)
+            return f"t{int(token_ids[0])}"
+    m.tokenizer = Fixed()
+    rec = {"zeroed": []}
+    real = itm.compute_gradcam_ensemble
+
+    def spy(args, model, visual_input, text_input, tokenized_text, drop_iter=0):
+        x = visual_input.detach().numpy()
+        P = cfg.grid
+        blk = x.reshape(x.shape[0], 3, P, 16, P, 16)
+        rec["zeroed"].append((np.abs(blk).sum(axis=(1, 3, 5)) == 0).reshape(x.shape[0], -1))
+        return real(args, model, visual_input, text_input, tokenized_text, drop_iter)
+    ns = RL.load_driver_functions(["Inference_BLIP_filteredcaption"], _driver_ns(itm))
+    ns["compute_gradcam_ensemble"] = spy
+    args = argparse.Namespace(img_size=336, drop_iter=4, max_att_block_num=8, prune_att_head="9", del_patch_num="sort_thresh005")
+    caps = ["x"] * B
+    tok500 = m.tokenizer(caps, padding="max_length", max_length=500)
+    norm_imgs = torch.zeros(B, 336, 336, 3)
+    g0, agg = ns["Inference_BLIP_filteredcaption"](args, RL.DDPLike(m), tok500, torch.from_numpy(imgs.copy()), norm_imgs,
+                                                   ["2007_000033", "2007_000042"], caps, [["c"] * n for n in ncls], "cpu")
+    np.savez_compressed(os.path.join(HERE, "droploop_large.npz"), cfg=json.dumps(cfg.as_dict()), weight_seed=0, image_seed=2024,
+                        token_seed=2024, n_classes=np.array(ncls), g0=g0.numpy().astype(np.float32),
+                        agg=agg.numpy().astype(np.float32), zeroed=np.stack(rec["zeroed"]))
+    print("droploop_large:", g0.shape, agg.shape, np.stack(rec["zeroed"]).sum(axis=(1, 2)))
 
 
 def gen_merge_tokens():
@@ -653,7 +700,7 @@ GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, gr
             pipeline_coco_object=gen_pipeline_coco_object, pipeline_coco_stuff=gen_pipeline_coco_stuff,
             gpt_parse_coco=gen_gpt_parse_coco, gpt_parse=gen_gpt_parse, tokenizer=gen_tokenizer,
             pos_embed=gen_pos_embed, checkpoint_small=gen_checkpoint_small,
-            blur_cases=gen_blur_cases, hist_cases=gen_hist_cases, preprocess_cases=gen_preprocess_cases)
+            droploop_large=gen_droploop_large, blur_cases=gen_blur_cases, hist_cases=gen_hist_cases, preprocess_cases=gen_preprocess_cases)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -663,6 +710,6 @@ if __name__ == "__main__":
     for name, fn in GENS.items():
         if a.only and name != a.only:
             continue
-        if a.skip_large and name in ("gradcam_large", "gradcam_large_768"):
+        if a.skip_large and name in ("gradcam_large", "gradcam_large_768", "droploop_large"):
             continue
         fn()

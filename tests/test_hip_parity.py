@@ -455,6 +455,15 @@ def test_gradcam_large_336_vs_reference_golden(bf16):
     else:
         assert np.abs(got - ref).max() < 0.1 * ref.max()
         assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).mean() < 0.03
+    if bf16 is not True:
+        # two more (layer, head) pairs from the same forward: layers 9 and 10 (the last layer's map [11][3] is identically
+        # zero -- only the dropped [ENC] row has a gradient there -- and would say nothing)
+        for layer, head, key in ((9, 3, "map_9_3"), (10, 5, "map_10_5")):
+            out2, _ = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), 25, head, layer=layer)
+            torch.cuda.synchronize()
+            assert g[key].max() > 0
+            assert np.abs(out2.cpu().numpy() - g[key]).max() < 1e-4
+            assert np.abs(_norm01(out2.cpu().numpy()[:, 3:-1]) - _norm01(g[key][:, 3:-1])).max() < (5e-3 if bf16 is False else 2e-2)
 
 
 # ------------------------------------------------------------------------------------------ post-process
@@ -862,6 +871,85 @@ def test_bf16_vs_f32_divergence_is_bounded():
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_drop_loop_large_vs_reference_golden(mode):
+    """The drop loop at FULL model size against the reference's own Inference_BLIP_filteredcaption run (PnP.py:564-722;
+    tests/golden/make_golden.py:gen_droploop_large): BLIP-ITM-large 336^2, B = 2 with ragged captions (20 and 12 classes:
+    the shorter row carries [SEP] and zero pad rows inside the [3:-1] salience slice), drop_iter 4.  Both parity modes must
+    pick the reference's patches in every (iteration, image) pair and hold north_star's 1e-4 on gradcam_0 / gradcam_agg;
+    with random weights the maps are ~1e-5 in size, so the per-token min-max normalised maps are compared as well."""
+    g = _golden("droploop_large.npz")
+    cfg = _cfg(g)
+    ncls = [int(x) for x in g["n_classes"]]
+    _, imgs = synth.synth_images(2, 336, seed=int(g["image_seed"]))
+    ids, mask = synth.synth_tokens(cfg, ncls, seed=int(g["token_seed"]))
+    L = int(mask.sum(1).max())
+    e = _engine(cfg, int(g["weight_seed"]), mode, max_batch=2, max_text_len=32)
+    g0, agg, picks, _ = e.drop_loop(_dev(imgs), _dev(ids), _dev(mask), L, 9, 4)
+    torch.cuda.synchronize()
+    picks = picks.cpu().numpy()
+    zeroed = g["zeroed"]                       # (iter, B, PP): patches the reference had zeroed BEFORE iteration k
+    assert zeroed.shape == (4, 2, 441) and zeroed[0].sum() == 0
+    for it in range(1, 4):
+        for b in range(2):
+            ref_set = set(np.nonzero(zeroed[it, b])[0].tolist())
+            assert len(ref_set) == 10 * it
+            assert ref_set == set(picks[b, : it * 10].tolist()), (mode, it, b, sorted(ref_set ^ set(picks[b, : it * 10].tolist())))
+    got0, gota = g0.cpu().numpy(), agg.cpu().numpy()
+    assert np.abs(got0 - g["g0"]).max() < 1e-4 and np.abs(gota - g["agg"]).max() < 1e-4
+    tol = 5e-3 if mode == "f32" else 2e-2
+    for b, n in enumerate(ncls):               # class rows only: rows past the caption are zero in both
+        sl = slice(3, 3 + n)
+        assert np.abs(_norm01(got0[b, sl]) - _norm01(g["g0"][b, sl])).max() < tol
+        assert np.abs(_norm01(gota[b, sl]) - _norm01(g["agg"][b, sl])).max() < tol
+
+
+def test_bf16x3_picks_equal_f32_at_blip_large_batch8():
+    """Pick parity of the benchmarked mode at full model size (what tools/precision_probe.py measured, as a test): eight
+    images through BLIP-ITM-large 336^2, drop_iter 4, 20-class prompt -- the split-bf16 mode must choose exactly the
+    patches the exact-fp32 mode chooses in all 8 x 4 (image, iteration) pairs, and its aggregated map must agree to 1e-4
+    absolute / 2 % of the per-token range."""
+    cfg = C.blip_itm_large(336)
+    B = 8
+    _, imgs = synth.synth_images(B, 336, seed=515)
+    ids, mask = synth.synth_tokens(cfg, [20] * B, seed=515)
+    L = int(mask.sum(1).max())
+    out = {}
+    for mode in ("f32", "bf16x3"):
+        e = _engine(cfg, 0, mode, max_batch=B, max_text_len=32)
+        g0, agg, picks, _ = e.drop_loop(_dev(imgs), _dev(ids), _dev(mask), L, 9, 4)
+        torch.cuda.synchronize()
+        out[mode] = (agg.cpu().numpy(), picks.cpu().numpy())
+    (af, pf), (ax, px) = out["f32"], out["bf16x3"]
+    bad = [(b, it) for b in range(B) for it in range(1, 5) if set(pf[b, : 10 * it].tolist()) != set(px[b, : 10 * it].tolist())]
+    assert not bad, f"pick sets differ in (image, iteration) pairs {bad}"
+    assert np.abs(ax - af).max() < 1e-4
+    assert np.abs(_norm01(ax[:, 3:-1]) - _norm01(af[:, 3:-1])).max() < 2e-2
+
+
+@pytest.mark.parametrize("n_classes", [150, 187])
+def test_gradcam_long_caption_vs_oracle(n_classes):
+    """Text path above 64 tokens: an ADE20K-sized caption (150 classes, L = 155) and the longest the engine takes (L = 192)
+    through the text self-attention / cross-attention / backward kernels, small geometry, against the oracle."""
+    cfg = C.blip_itm_small(128)
+    W = synth.synth_state_dict(cfg, 4)
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=9)
+    ids, mask = synth.synth_tokens(cfg, [n_classes, 7], seed=9)
+    L = int(mask.sum(1).max())
+    assert L == n_classes + 5 and L <= 192
+    for mode in ("f32", "bf16x3"):
+        e = _engine(cfg, 4, mode, max_batch=2, max_text_len=192)
+        out, logits = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 9)
+        torch.cuda.synchronize()
+        maps, ref_logits, _ = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7])
+        ref = maps[7][:, 9]
+        got = out.cpu().numpy()
+        assert got.shape == ref.shape == (2, L - 1, 8, 8)
+        assert np.abs(got - ref).max() < 1e-4
+        assert np.abs(_norm01(got[0, 3:-1]) - _norm01(ref[0, 3:-1])).max() < 2e-2
+        np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, rtol=0, atol=2e-2)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 def test_gradcam_large_768_vs_reference_golden(mode):
     """BASELINE config 5 at full model size: BLIP-ITM-large, img_size 768 (ViT re-tiled to 48 x 48 patches = 2305 image
     tokens), 40-class prompt (L = 45), B = 1, against the reference's own compute_gradcam_ensemble run
@@ -880,9 +968,13 @@ def test_gradcam_large_768_vs_reference_golden(mode):
     assert np.abs(got - ref).max() < 1e-4
     assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < (1e-2 if mode == "f32" else 3e-2)
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-2)
-    out2, _ = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 3, layer=11)
+    # a second (layer, head): layer 9 -- the last text layer's map is identically zero (only the dropped [ENC] row has a
+    # gradient there), so [11][3] says nothing
+    out2, _ = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 3, layer=9)
     torch.cuda.synchronize()
-    assert np.abs(out2.cpu().numpy() - g["map_11_3"]).max() < 1e-4
+    assert g["map_9_3"].max() > 0 and np.abs(g["map_11_3"]).max() == 0
+    assert np.abs(out2.cpu().numpy() - g["map_9_3"]).max() < 1e-4
+    assert np.abs(_norm01(out2.cpu().numpy()[:, 3:-1]) - _norm01(g["map_9_3"][:, 3:-1])).max() < (1e-2 if mode == "f32" else 3e-2)
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
