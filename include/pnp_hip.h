@@ -270,6 +270,13 @@ int pnp_op_gemm_x3(const void* d_A_hi, const void* d_A_lo, int32_t lda, const vo
                    int32_t M, int32_t N, int32_t K, const float* d_bias, int32_t bias_on_rows, const float* d_resid, int32_t ldr,
                    float* d_out_f32, int32_t ldo, void* d_out_hi, void* d_out_lo, int32_t ldo_t, int32_t gelu, int32_t col_div,
                    int32_t col_pad, void* stream);
+/* Text-side form of the split-bf16 Linear (B/med.py:201-228 query / key / value, :321-325 and :393-411 dense layers at
+ * M = B*L rows, and their backward): A is fp32 [M, lda] and is split into (hi, lo) bf16 by the kernel, the weight is a
+ * (hi, lo) bf16 pair; out[m, n] = act(A[m,:] . B[n,:] + bias[n]) (+ resid[m, n]) in fp32.
+ *   mode 0 linear | 1 erf GELU (pre-activation stashed to d_aux when given) | 2 multiply by GELU'(d_aux[m, n]). */
+int pnp_op_gemm_x3a(const float* d_A, int32_t lda, const void* d_B_hi, const void* d_B_lo, int32_t ldb, int32_t M, int32_t N,
+                    int32_t K, const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, int32_t mode,
+                    float* d_aux, int32_t ld_aux, void* stream);
 /* ViT self-attention of one block (B/vit.py:93-117): ctx = softmax(q k^T * scale) v per (image, head), head_dim 64.
  * d_qk [B*N, ld_qk]: q of head h at column h*64, k at column D + h*64; d_ctx [B*N, D].
  * fp32 mode: d_vt [D, ld_vt] = V^T, row h*64+d, column b*n_pad + token (n_pad a multiple of 64, pad columns zero).

@@ -253,6 +253,13 @@ __global__ void neighbors_kernel(const uint64_t* __restrict__ ukeys, const int* 
 
 // ------------------------------------------------------------------------------------------
 // Scalar (K = 1) lattice pass used once per batch for the normaliser: norm = 1/sqrt(L(1) + 1e-20).
+// One element of a lattice axis blur, densecrf's `old + 0.5 * (n1 + n2)` (double literal): (n1 + n2) is a float sum; the
+// product by 0.5 is exact; and the double sum old + 0.5 t, rounded to float, equals the single rounding of the exact sum
+// (it is exact in double whenever the exponents are within 28, and beyond that the small term is below a quarter ulp of the
+// float result on either path) -- i.e. one float fma.  Two VALU instructions per element instead of two conversions, an
+// fp64 multiply, an fp64 add and a conversion back; bit-identical to the oracle's double form (tests: GPU == oracle).
+__device__ __forceinline__ float crf_axis(float old, float n1, float n2) { return __fmaf_rn(0.5f, __fadd_rn(n1, n2), old); }
+
 __global__ void crf_splat1_kernel(const CrfLattice L, const PostDesc* __restrict__ imgs, float* __restrict__ val) {
     const int b = blockIdx.y;
     const int lo = L.idbase[b], hi = L.idbase[b + 1];
@@ -276,7 +283,7 @@ __global__ void crf_blur1_kernel(const CrfLattice L, const PostDesc* __restrict_
         const int a = n1[id], c = n2[id];
         const float va = a >= 0 ? src[a] : 0.f;
         const float vc = c >= 0 ? src[c] : 0.f;
-        dst[id] = (float)__dadd_rn((double)src[id], __dmul_rn(0.5, (double)__fadd_rn(va, vc)));
+        dst[id] = crf_axis(src[id], va, vc);
     }
 }
 
@@ -488,8 +495,8 @@ __global__ __launch_bounds__(256) void crf_blur4_kernel(const CrfLattice L, cons
             f32x4 o0, o1;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                o0[i] = (float)__dadd_rn((double)old0[i], __dmul_rn(0.5, (double)__fadd_rn(va0[i], vd0[i])));
-                o1[i] = (float)__dadd_rn((double)old1[i], __dmul_rn(0.5, (double)__fadd_rn(va1[i], vd1[i])));
+                o0[i] = crf_axis(old0[i], va0[i], vd0[i]);
+                o1[i] = crf_axis(old1[i], va1[i], vd1[i]);
             }
             D4[it0] = o0;
             if (two) D4[it1] = o1;
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(256) void crf_blur4_kernel(const CrfLattice L, cons
 __device__ __forceinline__ f32x4 crf_blur1(const f32x4& old, const f32x4& va, const f32x4& vd) {
     f32x4 o;
 #pragma unroll
-    for (int i = 0; i < 4; i++) o[i] = (float)__dadd_rn((double)old[i], __dmul_rn(0.5, (double)__fadd_rn(va[i], vd[i])));
+    for (int i = 0; i < 4; i++) o[i] = crf_axis(old[i], va[i], vd[i]);
     return o;
 }
 // The eight neighbour ids of a point for the axis pair (2p, 2p+1) come from one 32-byte record (CrfNbr8, image-local ids,

@@ -1552,6 +1552,17 @@ extern "C" int pnp_op_gemm_x3(const void* d_A_hi, const void* d_A_lo, int32_t ld
     return gemm_nt(1, g, (hipStream_t)stream);
 }
 
+extern "C" int pnp_op_gemm_x3a(const float* d_A, int32_t lda, const void* d_B_hi, const void* d_B_lo, int32_t ldb, int32_t M,
+                               int32_t N, int32_t K, const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32,
+                               int32_t ldo, int32_t mode, float* d_aux, int32_t ld_aux, void* stream) {
+    if (!d_A || !d_B_hi || !d_B_lo || !d_out_f32 || mode < 0 || mode > 2) return PNP_ERR_ARG;
+    GemmArgs g = G_(d_A, lda, d_B_hi, ldb, M, N, K);
+    g.B_lo = d_B_lo; g.a_f32 = 1;
+    g.bias = d_bias; g.resid = d_resid; g.ldr = ldr; g.out_f32 = d_out_f32; g.ldo = ldo;
+    g.mode = mode; g.aux = d_aux; g.ld_aux = ld_aux;
+    return gemm_nt(0, g, (hipStream_t)stream);
+}
+
 extern "C" int pnp_op_gemm_tokcols(int32_t bf, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N,
                                    int32_t K, const float* d_bias_rows, void* d_out_t, int32_t ldo_t, int32_t col_div,
                                    int32_t col_pad, void* stream) {

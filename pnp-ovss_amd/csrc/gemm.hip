@@ -1029,12 +1029,12 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
 // split into (hi, lo) bf16 ONCE by the threads that stage it (global -> registers -> two 16-byte LDS stores per 8 values),
 // the weight tile arrives by LDS-DMA already split, and each fragment pair issues three v_mfma_f32_16x16x32_bf16
 // (a_hi.b_lo, a_lo.b_hi, a_hi.b_hi: fp32-class product, see the wide kernel's X3 note).
-// Tile 64 x 64, 4 waves of 32 x 32, 32-deep k-slabs, 3-slot ring: slot = A_hi | A_lo | B_hi | B_lo, each 64 rows x 64 bytes,
+// Tile 64 x 64, 4 waves of 32 x 32, 32-deep k-slabs, 4-slot ring (three slabs in flight): slot = A_hi | A_lo | B_hi | B_lo, each 64 rows x 64 bytes,
 // 16-byte chunks swizzled chunk ^= (-(row >> 2)) & 3 (the 16 lanes a ds_read_b128 services together -- 4 rows of one q
 // and 8 rows of the next -- then hit 16 different slots).  Epilogue: the generic store_frag (bias, residual, GELU + stash,
 // GELU', fp32 outputs), same accumulator layout as gemm_nt_big_kernel.
 __global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g) {
-    constexpr int BM = 64, BN = 64, NS = 3, ARR = 64 * 64, SLOT = 4 * ARR;
+    constexpr int BM = 64, BN = 64, NS = 4, ARR = 64 * 64, SLOT = 4 * ARR;
     __shared__ __attribute__((aligned(16))) char smem[NS * SLOT];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1070,19 +1070,21 @@ __global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bl + (size_t)(b_off + koff)),
                                          (__attribute__((address_space(3))) void*)(st + ARR), 16, 0, 0);
     };
-    f32x4 ra0, ra1;                                   // the staged A values of the slab after next
+    // staged A values: two register sets, slab kt + 1 (stored to LDS in iteration kt) and slab kt + 2; a load has two
+    // iterations to land
+    f32x4 ra[2][2];
     auto load_a = [&](int kt) {
-        ra0 = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32);
-        ra1 = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32 + 4);
+        ra[kt & 1][0] = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32);
+        ra[kt & 1][1] = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32 + 4);
     };
     auto store_a = [&](int kt) {                      // x = hi + lo, both bf16 (round to nearest even)
         bf16x8 h, l;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            h[e] = (bf16)ra0[e];
-            l[e] = (bf16)(ra0[e] - (float)h[e]);
-            h[4 + e] = (bf16)ra1[e];
-            l[4 + e] = (bf16)(ra1[e] - (float)h[4 + e]);
+            h[e] = (bf16)ra[kt & 1][0][e];
+            l[e] = (bf16)(ra[kt & 1][0][e] - (float)h[e]);
+            h[4 + e] = (bf16)ra[kt & 1][1][e];
+            l[4 + e] = (bf16)(ra[kt & 1][1][e] - (float)h[4 + e]);
         }
         char* st = smem + (kt % NS) * SLOT + a_dst;
         *reinterpret_cast<bf16x8*>(st) = h;
@@ -1099,7 +1101,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g)
     const int fsw = (q ^ ((-(r >> 2)) & 3)) << 4;
     const int fa_off = (wm * 32 + r) * 64 + fsw, fb_off = 2 * ARR + (wn * 32 + r) * 64 + fsw;
 
-    // prologue: slab 0 (A written at once), slab 1 (A in registers, B in flight)
+    // prologue: slab 0 (A written at once); slabs 1 and 2 in flight (A in registers, B by DMA)
     load_a(0);
     issue_b(0);
     store_a(0);
@@ -1107,16 +1109,22 @@ __global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g)
         load_a(1);
         issue_b(1);
     }
-    for (int kt = 0; kt < nk; kt++) {
-        // slab kt complete for everybody: own B pieces of slab kt landed (at most slab kt+1's two pieces still in flight;
-        // the A loads in front of them are then done too), own A stores of slab kt done
-        if (kt + 1 < nk) PNP_WAIT_VM_LGKM(2);
+    if (nk > 2) {
+        load_a(2);
+        issue_b(2);
+    }
+    // main loop, two iterations per trip so that the register set indices are compile-time
+    auto iter = [&](int kt) {
+        // slab kt complete for everybody: own B pieces of slab kt landed and the A values of slab kt + 1 loaded; still in
+        // flight (issue order): B(kt+1) x 2 | A(kt+2) x 2, B(kt+2) x 2
+        if (kt + 2 < nk) PNP_WAIT_VM_LGKM(6);
+        else if (kt + 1 < nk) PNP_WAIT_VM_LGKM(2);
         else PNP_WAIT_VM_LGKM(0);
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) store_a(kt + 1);             // slot (kt+1) % 3 was last read in iteration kt-2
-        if (kt + 2 < nk) {
-            load_a(kt + 2);
-            issue_b(kt + 2);                          // slot (kt+2) % 3 was last read in iteration kt-1: free since this barrier
+        if (kt + 1 < nk) store_a(kt + 1);             // slot (kt+1) % 4 was last read in iteration kt-3
+        if (kt + 3 < nk) {
+            load_a(kt + 3);                           // into the register set store_a has just emptied
+            issue_b(kt + 3);                          // slot (kt+3) % 4 was last read in iteration kt-1: free since this barrier
         }
         const char* st = smem + (kt % NS) * SLOT;
         bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -1138,7 +1146,13 @@ __global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
             }
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        iter(kt);
+        iter(kt + 1);
     }
+    if (kt < nk) iter(kt);
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int m = m0 + wm * 32 + j * 16 + r;

@@ -8,7 +8,7 @@ f=$(find /tmp/ks_$TAG -name "*kernel_stats.csv" | head -1)
 python3 - "$f" > $R/gpurun_out/kstats_$TAG.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:16]:
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:40]:
     t = float(r["TotalDurationNs"]); c = int(r["Calls"])
     print(f"  {r['Name'][:80]:80s} calls {c:6d} total {t/1e6:8.2f} ms avg {t/c/1e3:8.1f} us")
 PY
