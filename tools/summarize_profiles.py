@@ -1,7 +1,7 @@
 """Turn the raw rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/<tag>_*) into the small committed summaries
 under profiles/: kernel-stats table, MFMA-busy table, HBM traffic per launch (FETCH_SIZE doubled for 16-byte-per-lane
 reads on gfx950, as MI355X_MICROARCH.md prescribes) for the GEMM and the CRF kernels.
-usage: python tools/summarize_profiles.py r02"""
+usage: python tools/summarize_profiles.py r03"""
 import collections
 import csv
 import json
@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -21,8 +21,9 @@ def short(name):
 def kernel_stats(sub, out):
     rows = list(csv.DictReader(open(os.path.join(G, f"{TAG}_{sub}", "prof_kernel_stats.csv"))))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    lines = [f"# rocprofv3 --kernel-trace --stats of `python3 bench.py {'--dtype bf16x3 ' if 'x3' in sub else ''}--steps 2 --warmup 1 "
-             f"--no-cpu-baseline --no-parity-mode --no-noise12` (3 steps of 35 images in the trace)",
+    lines = [f"# rocprofv3 --kernel-trace --stats of `python3 bench.py {'--dtype bf16 ' if 'bf16' in sub else ''}--steps 2 --warmup 1 "
+             f"--pipelines 1 --no-cpu-baseline --no-other-modes --no-other-configs --no-noise12` "
+             f"({'bf16 throughput mode' if 'bf16' in sub else 'headline mode bf16x3'}; 3 steps of 35 images in the trace)",
              "# kernel | calls | total ms | avg us | min us | max us | % of GPU time"]
     for r in rows:
         t = float(r["TotalDurationNs"])
@@ -46,15 +47,29 @@ def pmc(sub):
     return agg, n
 
 
+def traffic(fetch_sub, write_sub, note_extra=""):
+    fa, fn = pmc(fetch_sub)
+    wa, wn = pmc(write_sub)
+    tr = {"note": "HBM-side bytes per launch: FETCH_SIZE (KB, doubled: gfx950 reports half of wide coalesced reads) + WRITE_SIZE (KB)"
+                  + note_extra, "kernels": {}}
+    for k in fa:
+        c = fn[k]["FETCH_SIZE"]
+        w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(wn.get(k, {}).get("WRITE_SIZE", 1), 1)
+        f = fa[k]["FETCH_SIZE"] / c
+        tr["kernels"][k] = {"launches_profiled": c, "fetch_kb_raw": f, "write_kb": w,
+                            "traffic_bytes_per_launch": (2 * f + w) * 1024}
+    return tr
+
+
 def main():
     os.makedirs(P, exist_ok=True)
     kernel_stats("trace", f"{TAG}_bench_kernel_stats_summary.txt")
-    if os.path.exists(os.path.join(G, f"{TAG}_trace_x3")):
-        kernel_stats("trace_x3", f"{TAG}_bench_bf16x3_kernel_stats_summary.txt")
+    if os.path.exists(os.path.join(G, f"{TAG}_trace_bf16")):
+        kernel_stats("trace_bf16", f"{TAG}_bench_bf16_kernel_stats_summary.txt")
     agg, n = pmc("pmc_mfma")
-    out = {"note": "per launch; GRBM_GUI_ACTIVE is summed over the 8 XCDs (cycles = /8); SQ_VALU_MFMA_BUSY_CYCLES is summed over the "
-                   "1024 SIMDs; mfma_busy_frac = busy / (cycles * 1024): share of SIMD-cycles with the matrix pipe busy at the clock "
-                   "the chip actually held", "kernels": {}}
+    out = {"note": "headline mode (bf16x3), per launch; GRBM_GUI_ACTIVE is summed over the 8 XCDs (cycles = /8); SQ_VALU_MFMA_BUSY_CYCLES "
+                   "is summed over the 1024 SIMDs; mfma_busy_frac = busy / (cycles * 1024): share of SIMD-cycles with the matrix pipe "
+                   "busy at the clock the chip actually held", "kernels": {}}
     for k, v in agg.items():
         c = n[k]["GRBM_GUI_ACTIVE"]
         if not c or "SQ_VALU_MFMA_BUSY_CYCLES" not in v:
@@ -63,19 +78,14 @@ def main():
         out["kernels"][k] = {"launches": c, "cycles_per_launch": cyc, "mfma_busy_cycles_per_launch": v["SQ_VALU_MFMA_BUSY_CYCLES"] / c,
                              "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"] / c / (cyc * 1024)}
     json.dump(out, open(os.path.join(P, f"{TAG}_mfma_busy.json"), "w"), indent=1)
-    fa, fn = pmc("pmc_FETCH_SIZE")
-    wa, wn = pmc("pmc_WRITE_SIZE")
-    tr = {"note": "HBM-side bytes per launch: FETCH_SIZE (KB, doubled: gfx950 reports half of wide coalesced reads) + WRITE_SIZE (KB)",
-          "kernels": {}}
-    for k in fa:
-        c = fn[k]["FETCH_SIZE"]
-        w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(wn.get(k, {}).get("WRITE_SIZE", 1), 1)
-        f = fa[k]["FETCH_SIZE"] / c
-        tr["kernels"][k] = {"launches_profiled": c, "fetch_kb_raw": f, "write_kb": w,
-                            "traffic_bytes_per_launch": (2 * f + w) * 1024}
+    tr = traffic("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", " -- headline mode bf16x3")
     json.dump(tr, open(os.path.join(P, f"{TAG}_hbm_traffic.json"), "w"), indent=1)
     g = {k: v for k, v in tr["kernels"].items() if "gemm_nt_wide" in k}
-    json.dump({"note": tr["note"], "kernels": g}, open(os.path.join(P, f"{TAG}_gemm_traffic.json"), "w"), indent=1)
+    json.dump({"note": tr["note"], "kernels": g}, open(os.path.join(P, f"{TAG}_gemm_traffic_bf16x3.json"), "w"), indent=1)
+    if os.path.exists(os.path.join(G, f"{TAG}_pmc_bf16_FETCH_SIZE")):
+        tb = traffic("pmc_bf16_FETCH_SIZE", "pmc_bf16_WRITE_SIZE", " -- bf16 throughput mode")
+        json.dump({"note": tb["note"], "kernels": {k: v for k, v in tb["kernels"].items() if "gemm_nt_wide" in k}},
+                  open(os.path.join(P, f"{TAG}_gemm_traffic.json"), "w"), indent=1)
     try:
         ta, tn = pmc("pmc_tcc")
         json.dump({k: {"l2_hit_rate": v["TCC_HIT_sum"] / max(v["TCC_HIT_sum"] + v["TCC_MISS_sum"], 1)} for k, v in ta.items()},
