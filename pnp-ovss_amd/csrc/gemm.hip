@@ -592,8 +592,14 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                             rd_b(bhn, bln, kt_n, ks_n, 1);
                         }
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                    if constexpr (decltype(dma)::value) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                    if constexpr (decltype(dma)::value) {           // one piece behind every third MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                    }
                     if constexpr (decltype(refill)::value) {
                         if (j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                         else if (j == 1) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
