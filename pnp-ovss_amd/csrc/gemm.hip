@@ -1039,73 +1039,106 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
 // 16-byte chunks swizzled chunk ^= (-(row >> 2)) & 3 (the 16 lanes a ds_read_b128 services together -- 4 rows of one q
 // and 8 rows of the next -- then hit 16 different slots).  Epilogue: the generic store_frag (bias, residual, GELU + stash,
 // GELU', fp32 outputs), same accumulator layout as gemm_nt_big_kernel.
-__global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g) {
-    constexpr int BM = 64, BN = 64, NS = 4, ARR = 64 * 64, SLOT = 4 * ARR;
-    __shared__ __attribute__((aligned(16))) char smem[NS * SLOT];
+// NW = 4 (wave tile 32 x 32) or 8 waves (32 x 16: half the instructions per wave and slab, two waves per SIMD to overlap).
+// KS = k32 steps per slab (1: 32-deep, 64-byte LDS rows; 2: 64-deep, 128-byte rows swizzled like the wide bf16 kernel): these
+// launches move ~260 MB through L2 for a few GFLOP and run at the latency x bytes-in-flight of the CUs they occupy (168-672
+// workgroups), so the deeper slab (twice the bytes in flight per workgroup, half the barriers) is what the product launches.
+template <int NW, int KS>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArgs g) {
+    constexpr int BM = 64, BN = 64, ROWB = 64 * KS, ARR = 64 * ROWB, SLOT = 4 * ARR, NS = 4;
+    constexpr int WN = NW / 2, TN = 2 / (NW / 4);      // waves along n, 16-column tiles per wave (2 | 1); 2 row tiles per wave
+    constexpr int EPT = 32 * KS / NW;                  // staged A values per thread and slab (NW threads per row)
+    constexpr int PROWS = 1024 / ROWB;                 // rows of a 1 KB DMA piece (16 | 8)
+    constexpr int BP = 2 * (64 / PROWS) / NW;          // B DMA pieces per wave and slab (hi and lo arrays)
+    constexpr int VMI = (EPT + 3) / 4 + BP;            // vector-memory operations a wave issues per slab (16-byte A loads + B pieces)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int nbn = g.N / BN;
-    const int bm = blockIdx.x / nbn, bn = blockIdx.x - bm * nbn;
+    const int wm = wave / WN, wn = wave % WN;
+    // XCD-grouped, column-major tile order: the workgroups of one XCD (blockIdx.x % 8) take a contiguous run of tile ids =
+    // a few column tiles x all row tiles, so an XCD's L2 holds its slice of the weight and the activations instead of
+    // every XCD streaming the whole weight from the Infinity Cache
+    const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
+    int bm, bn;
+    tile_coords<16>(blockIdx.x, nbm, nbn, bm, bn);
     const int m0 = bm * BM, n0 = bn * BN;
-    const int nk = g.K / 32;
+    const int nk = g.K / (32 * KS);
+    auto swz = [](int row) { return KS == 1 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7); };
 
-    // A staging: thread -> row tid / 4, k elements 8 (tid % 4) .. + 7 of the slab (32 bytes of fp32)
-    const int a_row = tid >> 2, a_c = tid & 3;
+    // A staging: thread -> row tid / NW, EPT consecutive k values of the slab (fp32)
+    const int a_row = tid / NW, a_e = (tid % NW) * EPT;
     int a_gr = m0 + a_row;
     a_gr = a_gr < g.M ? a_gr : g.M - 1;
-    const float* a_src = reinterpret_cast<const float*>(g.A) + (size_t)a_gr * g.lda + a_c * 8;
-    const int a_dst = a_row * 64 + ((a_c ^ ((-(a_row >> 2)) & 3)) << 4);
-    // B DMA: wave w moves rows 16 w .. + 15 of B_hi and of B_lo (one 1 KB piece each per slab)
+    const float* a_src = reinterpret_cast<const float*>(g.A) + (size_t)a_gr * g.lda + a_e;
+    // B DMA: pieces of PROWS rows; piece p of the slab: array (hi | lo) = p / (64 / PROWS), rows PROWS (p % (64 / PROWS)) ..
     const char* Bh = reinterpret_cast<const char*>(g.B);
     const char* Bl = reinterpret_cast<const char*>(g.B_lo);
-    uint32_t b_off;
-    {
-        const int row = wave * 16 + (lane >> 2);
+    constexpr int PPA = 64 / PROWS, LPR = ROWB / 16;   // pieces per array, lanes per row
+    uint32_t b_off[BP];
+#pragma unroll
+    for (int i = 0; i < BP; i++) {
+        const int p = wave * BP + i;
+        const int row = (p % PPA) * PROWS + lane / LPR;
         int gr = n0 + row;
         gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
-        const int c = (lane & 3) ^ ((-(row >> 2)) & 3);
-        b_off = (uint32_t)gr * (uint32_t)g.ldb * 2 + c * 16;
+        const int c = (lane % LPR) ^ swz(row);
+        b_off[i] = (uint32_t)gr * (uint32_t)g.ldb * 2 + c * 16;
     }
     auto issue_b = [&](int kt) {
-        char* st = smem + (kt % NS) * SLOT + 2 * ARR + wave * 1024;
-        const uint32_t koff = (uint32_t)kt * 64;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bh + (size_t)(b_off + koff)),
-                                         (__attribute__((address_space(3))) void*)st, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Bl + (size_t)(b_off + koff)),
-                                         (__attribute__((address_space(3))) void*)(st + ARR), 16, 0, 0);
+        char* st = smem + (kt % NS) * SLOT + 2 * ARR;
+        const uint32_t koff = (uint32_t)kt * ROWB;
+#pragma unroll
+        for (int i = 0; i < BP; i++) {
+            const int p = wave * BP + i;               // uniform
+            const char* base = p < PPA ? Bh : Bl;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(b_off[i] + koff)),
+                                             (__attribute__((address_space(3))) void*)(st + (p / PPA) * ARR + (p % PPA) * 1024), 16, 0, 0);
+        }
     };
     // staged A values: two register sets, slab kt + 1 (stored to LDS in iteration kt) and slab kt + 2; a load has two
     // iterations to land
-    f32x4 ra[2][2];
-    auto load_a = [&](int kt) {
-        ra[kt & 1][0] = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32);
-        ra[kt & 1][1] = *reinterpret_cast<const f32x4*>(a_src + (size_t)kt * 32 + 4);
-    };
+    typedef __attribute__((ext_vector_type(EPT))) float fvec;
+    fvec ra[2];
+    auto load_a = [&](int kt) { ra[kt & 1] = *reinterpret_cast<const fvec*>(a_src + (size_t)kt * (32 * KS)); };
     auto store_a = [&](int kt) {                      // x = hi + lo, both bf16 (round to nearest even)
-        bf16x8 h, l;
+        char* st = smem + (kt % NS) * SLOT + a_row * ROWB;
+        if constexpr (EPT >= 8) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            h[e] = (bf16)ra[kt & 1][0][e];
-            l[e] = (bf16)(ra[kt & 1][0][e] - (float)h[e]);
-            h[4 + e] = (bf16)ra[kt & 1][1][e];
-            l[4 + e] = (bf16)(ra[kt & 1][1][e] - (float)h[4 + e]);
+            for (int c8 = 0; c8 < EPT / 8; c8++) {
+                bf16x8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    h[e] = (bf16)ra[kt & 1][c8 * 8 + e];
+                    l[e] = (bf16)(ra[kt & 1][c8 * 8 + e] - (float)h[e]);
+                }
+                const int off = (((a_e >> 3) + c8) ^ swz(a_row)) << 4;
+                *reinterpret_cast<bf16x8*>(st + off) = h;
+                *reinterpret_cast<bf16x8*>(st + ARR + off) = l;
+            }
+        } else {
+            bf16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                h[e] = (bf16)ra[kt & 1][e];
+                l[e] = (bf16)(ra[kt & 1][e] - (float)h[e]);
+            }
+            const int off = (((a_e >> 3) ^ swz(a_row)) << 4) + (a_e & 7) * 2;
+            *reinterpret_cast<bf16x4*>(st + off) = h;
+            *reinterpret_cast<bf16x4*>(st + ARR + off) = l;
         }
-        char* st = smem + (kt % NS) * SLOT + a_dst;
-        *reinterpret_cast<bf16x8*>(st) = h;
-        *reinterpret_cast<bf16x8*>(st + ARR) = l;
     };
 
-    f32x4 acc[2][2];
+    f32x4 acc[TN][2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TN; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment offsets: row of the 16-row tile = r, k = 8 q .. 8 q + 7 -> logical chunk q
-    const int fsw = (q ^ ((-(r >> 2)) & 3)) << 4;
-    const int fa_off = (wm * 32 + r) * 64 + fsw, fb_off = 2 * ARR + (wn * 32 + r) * 64 + fsw;
+    // fragment offsets: row of the 16-row tile = r, k = 32 ks + 8 q .. + 7 -> logical chunk 4 ks + q; tile row offsets are
+    // multiples of 16, which leave both swizzles unchanged
+    const int fa_row = (wm * 32 + r) * ROWB, fb_row = 2 * ARR + (wn * 16 * TN + r) * ROWB;
+    const int fsw = swz(r);
 
     // prologue: slab 0 (A written at once); slabs 1 and 2 in flight (A in registers, B by DMA)
     load_a(0);
@@ -1119,64 +1152,101 @@ __global__ __launch_bounds__(256) void gemm_nt_small_x3_kernel(const GemmArgs g)
         load_a(2);
         issue_b(2);
     }
-    // main loop, two iterations per trip so that the register set indices are compile-time
-    auto iter = [&](int kt) {
+    // one k-slab; REST = slabs behind kt that exist (3+: steady state, compile-time so the loop body has no branches)
+    auto iter = [&](int kt, auto rest) {
+        constexpr int REST = decltype(rest)::value;
         // slab kt complete for everybody: own B pieces of slab kt landed and the A values of slab kt + 1 loaded; still in
-        // flight (issue order): B(kt+1) x 2 | A(kt+2) x 2, B(kt+2) x 2
-        if (kt + 2 < nk) PNP_WAIT_VM_LGKM(6);
-        else if (kt + 1 < nk) PNP_WAIT_VM_LGKM(2);
+        // flight (issue order): B(kt+1) | A(kt+2), B(kt+2)
+        if constexpr (REST >= 2) PNP_WAIT_VM_LGKM(BP + VMI);
+        else if constexpr (REST == 1) PNP_WAIT_VM_LGKM(BP);
         else PNP_WAIT_VM_LGKM(0);
         __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) store_a(kt + 1);             // slot (kt+1) % 4 was last read in iteration kt-3
-        if (kt + 3 < nk) {
+        // fragment reads first: their latency runs under the conversion of the next slab's A values
+        const char* st = smem + (kt % NS) * SLOT;
+        bf16x8 ah[KS][2], al[KS][2], bh[KS][TN], bl[KS][TN];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            const int co = ((ks * 4 + q) ^ fsw) << 4;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                ah[ks][j] = *reinterpret_cast<const bf16x8*>(st + fa_row + j * 16 * ROWB + co);
+                al[ks][j] = *reinterpret_cast<const bf16x8*>(st + ARR + fa_row + j * 16 * ROWB + co);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; i++) {
+                bh[ks][i] = *reinterpret_cast<const bf16x8*>(st + fb_row + i * 16 * ROWB + co);
+                bl[ks][i] = *reinterpret_cast<const bf16x8*>(st + ARR + fb_row + i * 16 * ROWB + co);
+            }
+        }
+        if constexpr (REST >= 1) store_a(kt + 1);     // slot (kt+1) % 4 was last read in iteration kt-3
+        if constexpr (REST >= 3) {
             load_a(kt + 3);                           // into the register set store_a has just emptied
             issue_b(kt + 3);                          // slot (kt+3) % 4 was last read in iteration kt-1: free since this barrier
         }
-        const char* st = smem + (kt % NS) * SLOT;
-        bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            ah[j] = *reinterpret_cast<const bf16x8*>(st + fa_off + j * 16 * 64);
-            al[j] = *reinterpret_cast<const bf16x8*>(st + ARR + fa_off + j * 16 * 64);
-        }
+        for (int ks = 0; ks < KS; ks++)
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            bh[i] = *reinterpret_cast<const bf16x8*>(st + fb_off + i * 16 * 64);
-            bl[i] = *reinterpret_cast<const bf16x8*>(st + ARR + fb_off + i * 16 * 64);
-        }
+            for (int i = 0; i < TN; i++)
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < 2; j++) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[i], ah[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], al[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[i], ah[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < 2; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks][i], ah[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks][i], al[ks][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks][i], ah[ks][j], acc[i][j], 0, 0, 0);
+                }
     };
+    constexpr std::integral_constant<int, 3> r3{};
+    constexpr std::integral_constant<int, 2> r2{};
+    constexpr std::integral_constant<int, 1> r1{};
+    constexpr std::integral_constant<int, 0> r0{};
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        iter(kt);
-        iter(kt + 1);
+    for (; kt + 4 < nk; kt += 2) {                    // two iterations per trip: the register set indices are compile-time
+        iter(kt, r3);
+        iter(kt + 1, r3);
     }
-    if (kt < nk) iter(kt);
+    for (; kt < nk; kt++) {                           // the last (up to four) slabs
+        const int rest = nk - 1 - kt;
+        if (rest >= 3) iter(kt, r3);
+        else if (rest == 2) iter(kt, r2);
+        else if (rest == 1) iter(kt, r1);
+        else iter(kt, r0);
+    }
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int m = m0 + wm * 32 + j * 16 + r;
         if (m >= g.M) continue;
         const RowCtx rc = row_ctx(g, m);
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int n = n0 + wn * 32 + i * 16 + q * 4;
+        for (int i = 0; i < TN; i++) {
+            const int n = n0 + wn * 16 * TN + i * 16 + q * 4;
             if (n >= g.Nvalid) continue;
             store_frag<float>(g, rc, acc[i][j], m, n);
         }
     }
 }
 
-static int launch_small_x3(const GemmArgs& g, hipStream_t s) {
+template <int NW, int KS>
+static int launch_small_x3_t(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 63) / 64, nbn = g.N / 64;
-    hipLaunchKernelGGL(gemm_nt_small_x3_kernel, dim3(nbm * nbn), dim3(256), 0, s, g);
+    constexpr int smem = 4 * 4 * 64 * 64 * KS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small_x3_kernel<NW, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
+            hipSuccess)
+            return PNP_ERR_HIP;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_small_x3_kernel<NW, KS>), dim3(nbm * nbn), dim3(NW * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+static int launch_small_x3(const GemmArgs& g, hipStream_t s) {
+    int nw = 8, ks = g.K % 64 == 0 ? 2 : 1;
+#ifdef PNP_DEV
+    if (getenv("PNP_SMALL_NW")) nw = atoi(getenv("PNP_SMALL_NW"));
+    if (getenv("PNP_SMALL_KS") && atoi(getenv("PNP_SMALL_KS")) == 1) ks = 1;
+#endif
+    if (ks == 2) return nw == 4 ? launch_small_x3_t<4, 2>(g, s) : launch_small_x3_t<8, 2>(g, s);
+    return nw == 4 ? launch_small_x3_t<4, 1>(g, s) : launch_small_x3_t<8, 1>(g, s);
 }
 
 template <typename T, int BM, int BN>
