@@ -515,10 +515,14 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ ma
                 if (v > mx || v != v) mx = v;
             }
             float s = 0.f;
-            for (int k = 0; k < K; k++) s = __fadd_rn(s, pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)));
             float* row = utile + tid * ldt;
+            for (int k = 0; k < K; k++) {                              // the exponentials are parked in the tile: one exp per
+                const float e = pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx));   // element instead of two (same values)
+                row[k] = e;
+                s = __fadd_rn(s, e);
+            }
             for (int k = 0; k < K; k++) {
-                float p = __fdiv_rn(pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx)), s);
+                float p = __fdiv_rn(row[k], s);
                 if (p < 1e-5f) p = 1e-5f;
                 else if (p > 1.0f) p = 1.0f;
                 row[k] = -pnp_logf(p);
