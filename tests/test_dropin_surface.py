@@ -293,6 +293,39 @@ def test_build_model_from_checkpoint_matches_reference_load_checkpoint(tmp_path,
     model.engine.close()
 
 
+def test_lazy_model_from_checkpoint_retiles_pos_embed_at_first_call(tmp_path, golden_dir, monkeypatch):
+    """The reference's argument-less load (PnP.py:1212) with a checkpoint: the lazy model keeps the checkpoint's own pos-embed
+    grid in its buffers and re-tiles it (base_model.py:108-110) when the first compute_gradcam_ensemble(args, ...) fixes the
+    geometry -- same map as the reference model after its own load_checkpoint (golden checkpoint_small.npz)."""
+    import argparse as ap
+    from pnp_ovss import config as C, synth
+    from lavis.models import load_model_and_preprocess
+    from lavis.models.blip_models.blip_image_text_matching import compute_gradcam_ensemble
+    g = np.load(os.path.join(golden_dir, "checkpoint_small.npz"))
+    cfgd = json.loads(str(g["cfg"]))
+    cfg = C.ModelCfg(**cfgd)
+    cfg_ck = C.ModelCfg(**json.loads(str(g["cfg_ckpt"])))
+    ck = synth.synth_checkpoint(cfg, cfg_ck, int(g["ckpt_seed"]))
+    path = str(tmp_path / "ckpt.pth")
+    torch.save({"model": {k: torch.from_numpy(v.copy()) for k, v in ck.items()}}, path)
+    (tmp_path / "model.json").write_text(json.dumps(dict(cfgd, weight_seed=int(g["init_seed"]))))
+    monkeypatch.setenv("PNP_OVSS_MODEL_CONFIG", str(tmp_path / "model.json"))
+    monkeypatch.setenv("PNP_OVSS_CHECKPOINT", path)
+    monkeypatch.delenv("PNP_OVSS_DTYPE", raising=False)
+    with pytest.warns(UserWarning, match="itm_head.bias"):
+        model, _, _ = load_model_and_preprocess("blip_image_text_matching", "large", device=0, is_eval=True)
+    assert model._engine is None and model.pos_embed_raw.shape[1] == cfg_ck.n_img_tokens      # the checkpoint's grid, not yet re-tiled
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=int(g["image_seed"]))
+    caps = [str(c) for c in g["captions"]]
+    tok500 = model.module.tokenizer(caps, padding="max_length", max_length=500, return_tensors="pt")
+    args = ap.Namespace(img_size=cfg.img_size, max_att_block_num=8, prune_att_head="9", batch_size=2)
+    blocks, _, logits = compute_gradcam_ensemble(args, model.module, torch.from_numpy(imgs), caps, tok500)
+    assert model.engine.mode == "f32" and model.engine.cfg.img_size == cfg.img_size
+    assert np.abs(blocks[7][9].numpy() - g["map_7_9"]).max() < 1e-4
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], atol=5e-3)
+    model.engine.close()
+
+
 def test_compute_gradcam_ensemble_full_return_value_all_layers_and_heads(golden_dir):
     """f-4 (layer / head sweep): with stash_layer = 0 every [layer][head] entry of compute_gradcam_ensemble's return value
     (blip_image_text_matching.py:411-435, 12 x 12 maps) comes out of ONE forward -- against the reference's own 144 maps;
