@@ -412,7 +412,8 @@ def run_rank(a):
             run([steps // P + (1 if p < steps % P else 0) for p in range(P)])
             coll.barrier()
             torch.cuda.synchronize()
-            dt = coll.max_time(time.perf_counter() - t0, dev)
+            self.local_dt = time.perf_counter() - t0      # this rank's own time (the line's value uses the max over ranks)
+            dt = coll.max_time(self.local_dt, dev)
             return dt, states
 
         def timed_run(self, noise, steps, warmup, overlap=False, separate=False):
@@ -465,6 +466,7 @@ def run_rank(a):
             run(steps)
             sync()
             dt = time.perf_counter() - t0
+            self.local_dt = dt
             gemm = e.profile_read_stage(0)
             crf = e.profile_read_stage(1)
             e.profile_enable(False)
@@ -554,7 +556,7 @@ def run_rank(a):
     t_reduce = time.perf_counter() - t0
     per_rank = None
     if distributed:
-        mine = torch.tensor([wl.B * a.steps / (head["ms_per_step"] * a.steps * 1e-3)], device=dev, dtype=torch.float64)
+        mine = torch.tensor([wl.B * a.steps / wl.local_dt], device=dev, dtype=torch.float64)     # own clock, not the max over ranks
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [float(x.item()) for x in allr]
