@@ -8,6 +8,8 @@
 //   threshold / upsample / Scale_0_1 / background   PnP.py:348-379, 424-455, 1078-1094
 //   blur        PnP.py:1149-1153 (scipy.ndimage.gaussian_filter: reflect, truncate 4, double acc)
 //   remap/hist  PnP.py:390-399, 1106-1146
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "../../include/pnp_math.h"
@@ -327,14 +329,15 @@ __device__ __forceinline__ int reflect_fast(int i, int n) {
     return (m >= 0 && m < n) ? m : reflect_idx(i, n);
 }
 
-// LDS-tiled separable pass: a workgroup stages its 32 x 64 output tile + halo once; 256 threads x 8
-// consecutive outputs each.
-//   axis 0 (vertical):   xs[(32 + 2r)][64],        thread = (column c, row group of 8)
-//   axis 1 (horizontal): xs[32][colsP], colsP = 64 + 2r rounded up to odd (conflict-free row stride),
-//                        thread = (row, column group of 8)
+// LDS-tiled separable pass: a workgroup stages its output tile + halo once.  The tile is NT sub-tiles long ALONG the filtered
+// axis (a halo of 2 x radius samples is paid once per tile: at radius 67 a 32-row tile stages 5.2 samples per output, a
+// 128-row tile 2.0; at radius 154 -- ADE20K at 768^2 -- 10.6 against 3.4), 256 threads x 8 consecutive outputs per sub-tile.
+//   axis 0 (vertical):   xs[(32 NT + 2r)][64],     thread = (column c, row group of 8) per sub-tile
+//   axis 1 (horizontal): xs[32][colsP], colsP = 64 NT + 2r rounded up to odd (conflict-free row stride),
+//                        thread = (row, column group of 8) per sub-tile
 __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const PostDesc* __restrict__ desc, const double* __restrict__ wts,
-                                                        const int32_t* __restrict__ wt_off, int axis, int max_radius) {
+                                                        const int32_t* __restrict__ wt_off, int axis, int max_radius, int NT) {
     constexpr int TH = 32, TW = 64;
     extern __shared__ __attribute__((aligned(16))) double tile[];
     double* wl = tile;                                                   // [max_radius + 1] taps
@@ -343,21 +346,22 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
     const PostDesc d = desc[b];
     if (k >= d.K) return;
     const int H = d.H, W = d.W;
-    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int THe = axis == 0 ? TH * NT : TH, TWe = axis == 1 ? TW * NT : TW;     // tile extent (outputs)
+    const int tiles_x = (W + TWe - 1) / TWe, tiles_y = (H + THe - 1) / THe;
     const double* w = wts + wt_off[b];
     const int radius = wt_off[b + 1] - wt_off[b] - 1;
     const float* src = in + d.off + (size_t)k * H * W;
     float* dst = out + d.off + (size_t)k * H * W;
     const int tid = threadIdx.x;
     for (int j = tid; j <= radius; j += 256) wl[j] = w[j];
-    const int colsP = (TW + 2 * radius) | 1;
+    const int colsP = (TWe + 2 * radius) | 1;
     for (int tl = blockIdx.x; tl < tiles_x * tiles_y; tl += gridDim.x) {
         const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
-        const int y0 = ty * TH, x0 = tx * TW;
+        const int y0 = ty * THe, x0 = tx * TWe;
         __syncthreads();
         double acc[8];
         if (axis == 0) {
-            const int rows = TH + 2 * radius;            // xs[rows][TW]
+            const int rows = THe + 2 * radius;           // xs[rows][TW]
             const int c = tid & 63;
             const int x = x0 + c < W ? x0 + c : W - 1;
             // eight independent loads in flight per thread (a one-load-per-iteration loop made the whole kernel
@@ -376,12 +380,15 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
                 }
             }
             __syncthreads();
-            const int rg = tid >> 6;
-            blur_window8(xs + (size_t)(rg * 8 + radius) * TW + c, TW, wl, radius, acc);
-            if (x0 + c < W) {
+            for (int nt = 0; nt < NT; nt++) {
+                const int rg = nt * 4 + (tid >> 6);
+                if (y0 + rg * 8 >= H) break;
+                blur_window8(xs + (size_t)(rg * 8 + radius) * TW + c, TW, wl, radius, acc);
+                if (x0 + c < W) {
 #pragma unroll
-                for (int i = 0; i < 8; i++)
-                    if (y0 + rg * 8 + i < H) dst[(size_t)(y0 + rg * 8 + i) * W + x0 + c] = (float)acc[i];
+                    for (int i = 0; i < 8; i++)
+                        if (y0 + rg * 8 + i < H) dst[(size_t)(y0 + rg * 8 + i) * W + x0 + c] = (float)acc[i];
+                }
             }
         } else {
             // flat (row, column) index so all 256 threads load, eight independent loads in flight each
@@ -402,17 +409,21 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
                 }
             }
             __syncthreads();
-            const int rr = tid & 31, cg = tid >> 5;
-            blur_window8(xs + (size_t)rr * colsP + radius + cg * 8, 1, wl, radius, acc);
-            if (y0 + rr < H) {
-                float* o = dst + (size_t)(y0 + rr) * W + x0 + cg * 8;
-                if (x0 + cg * 8 + 7 < W && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
-                    reinterpret_cast<f32x4*>(o)[0] = f32x4{(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
-                    reinterpret_cast<f32x4*>(o)[1] = f32x4{(float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]};
-                } else {
+            const int rr = tid & 31;
+            for (int nt = 0; nt < NT; nt++) {
+                const int cg = nt * 8 + (tid >> 5);
+                if (x0 + cg * 8 >= W) break;
+                blur_window8(xs + (size_t)rr * colsP + radius + cg * 8, 1, wl, radius, acc);
+                if (y0 + rr < H) {
+                    float* o = dst + (size_t)(y0 + rr) * W + x0 + cg * 8;
+                    if (x0 + cg * 8 + 7 < W && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                        reinterpret_cast<f32x4*>(o)[0] = f32x4{(float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]};
+                        reinterpret_cast<f32x4*>(o)[1] = f32x4{(float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]};
+                    } else {
 #pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (x0 + cg * 8 + i < W) o[i] = (float)acc[i];
+                        for (int i = 0; i < 8; i++)
+                            if (x0 + cg * 8 + i < W) o[i] = (float)acc[i];
+                    }
                 }
             }
         }
@@ -667,10 +678,30 @@ int background_channel(float* maps, const PostDesc* desc, int B, int maxHW, hipS
 
 int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, const double* wts, const int32_t* wt_off,
               int B, int Kmax, int maxH, int maxW, int max_radius, hipStream_t s) {
-    const size_t lds0 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)(32 + 2 * max_radius) * 64 * sizeof(float);
-    const size_t lds1 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)32 * ((64 + 2 * max_radius) | 1) * sizeof(float);
-    const size_t need = lds0 > lds1 ? lds0 : lds1;
-    if (need > 160 * 1024) return PNP_ERR_ARG;            // radius <= ~300 (images up to ~1500 px on the long side)
+    // sub-tiles per tile along the filtered axis.  Small radii (67 at 336^2: 43 KB per 32-row tile, three workgroups per CU
+    // overlap each other's staging) keep one; once the halo alone leaves one workgroup per CU (radius 154 at 768^2: 87 KB)
+    // nothing overlaps the staging any more and the tile grows to as many as fit ~120 KB (at most 4): 23.5 -> 18.2 ms per
+    // launch at ADE20K size, where a 1-sub-tile launch at radius 67 is 6 % faster than a 4-sub-tile one
+    auto lds_for = [&](int n, size_t& l0, size_t& l1) {
+        l0 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)(32 * n + 2 * max_radius) * 64 * sizeof(float);
+        l1 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)32 * ((64 * n + 2 * max_radius) | 1) * sizeof(float);
+    };
+    size_t lds0, lds1;
+    lds_for(1, lds0, lds1);
+    int nt = lds0 > 80 * 1024 ? 4 : 1;
+#ifdef PNP_DEV
+    if (getenv("PNP_BLUR_NT")) nt = atoi(getenv("PNP_BLUR_NT"));
+#endif
+    lds_for(nt, lds0, lds1);
+    while (nt > 1 && (lds0 > 120 * 1024 || lds1 > 120 * 1024)) lds_for(--nt, lds0, lds1);
+    if (lds0 > 160 * 1024 || lds1 > 160 * 1024) return PNP_ERR_ARG;            // radius <= ~300 (images up to ~1500 px on the long side)
+    int nt0 = nt, nt1 = nt;
+    while (nt0 > 1 && 32 * (nt0 - 1) >= maxH) nt0--;                          // no taller / wider than the image
+    while (nt1 > 1 && 64 * (nt1 - 1) >= maxW) nt1--;
+    lds_for(nt0, lds0, lds1);
+    size_t d0, d1;
+    lds_for(nt1, d0, d1);
+    lds1 = d1;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(blur_axis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -678,9 +709,10 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
             return PNP_ERR_HIP;
         attr_set = true;
     }
-    const int tiles = ((maxW + 63) / 64) * ((maxH + 31) / 32);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles, Kmax, B), dim3(256), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles, Kmax, B), dim3(256), lds1, s, tmp, out, desc, wts, wt_off, 1, max_radius);
+    const int tiles0 = ((maxW + 63) / 64) * ((maxH + 32 * nt0 - 1) / (32 * nt0));
+    const int tiles1 = ((maxW + 64 * nt1 - 1) / (64 * nt1)) * ((maxH + 31) / 32);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles0, Kmax, B), dim3(256), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius, nt0);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles1, Kmax, B), dim3(256), lds1, s, tmp, out, desc, wts, wt_off, 1, max_radius, nt1);
     return ok();
 }
 

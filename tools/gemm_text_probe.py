@@ -13,7 +13,7 @@ from pnp_ovss import hip
 if "--dev" in sys.argv:
     hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), "libpnp_hip_dev.so")
 lib = hip.load_library()
-M = 875
+M = int([a for a in sys.argv[1:] if a.isdigit()][0]) if any(a.isdigit() for a in sys.argv[1:]) else 875
 
 
 def timeit(call, n=200):
