@@ -1023,7 +1023,11 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
         attr_set = true;
     }
     const int ntiles = nbm * nbn;
-    const int grid = ntiles > n_cu ? n_cu : ntiles;      // one workgroup per CU (LDS-limited) walks the tiles
+    int cap = n_cu;
+#ifdef PNP_DEV
+    if (getenv("PNP_GEMM_GRID")) cap = atoi(getenv("PNP_GEMM_GRID"));
+#endif
+    const int grid = ntiles > cap ? cap : ntiles;        // one workgroup per CU (LDS-limited) walks the tiles
     hipLaunchKernelGGL((gemm_nt_wide_kernel<EPI, X3>), dim3(grid), dim3(512), kWideSmem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
