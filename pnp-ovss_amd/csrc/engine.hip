@@ -204,6 +204,39 @@ __global__ void transpose_cast_kernel_f32(const float* __restrict__ in, float* _
     }
 }
 
+// The two extra layouts the analytic backward reads (V token-major for text layers >= stash_layer, K^T feature-major for
+// layers > stash_layer) as 32 x 32 LDS transposes of what the forward's two cross K / V GEMMs have just written, instead of
+// two more GEMMs over the same products (split-bf16 mode: 0.56 ms of GEMM per forward against 0.18 ms of copies; the copies
+// are also bit-identical to the forward's values, which two GEMMs with swapped operand roles are not).
+//   feat_to_tok: src [R features, ld_src] with token column b * n_pad + t  ->  dst [(b * N + t), R]
+__global__ void feat_to_tok_kernel(const float* __restrict__ src, int ld_src, int n_pad, float* __restrict__ dst, int R, int N) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, tok = t0 + threadIdx.x;
+        t[i][threadIdx.x] = (r < R && tok < N) ? src[(size_t)r * ld_src + (size_t)b * n_pad + tok] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int tok = t0 + i, r = r0 + threadIdx.x;
+        if (r < R && tok < N) dst[((size_t)b * N + tok) * R + r] = t[threadIdx.x][i];
+    }
+}
+//   tok_to_feat: src [(b * N + t), ld_src] columns c0 .. c0 + R  ->  dst [R features, ld_dst] at token column b * n_pad + t
+__global__ void tok_to_feat_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int ld_dst, int n_pad, int R, int N) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int tok = t0 + i, r = r0 + threadIdx.x;
+        t[i][threadIdx.x] = (r < R && tok < N) ? src[((size_t)b * N + tok) * ld_src + r] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += 8) {
+        const int r = r0 + i, tok = t0 + threadIdx.x;
+        if (r < R && tok < N) dst[(size_t)r * ld_dst + (size_t)b * n_pad + tok] = t[threadIdx.x][i];
+    }
+}
+
 // fp32 [rows, cols] staging -> compute-type device weight (optionally transposed); split: a bf16 (hi | lo) pair in
 // the same bytes as the fp32 copy, hi first (split-bf16 mode, weights of the wide GEMMs)
 int make_weight(pnp_engine* e, const float* src32, int rows, int cols, bool transpose, void** out, bool split = false) {
@@ -765,21 +798,15 @@ extern "C" int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream) {
             g.bias = e->cv_b; g.bias_on_rows = 1; g.out_f32 = (float*)e->Vt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
             KCHK(e, egemm(e, 1, g, s));
         }
-        {
-            const int nVn = TL - SL;
-            const size_t off = (size_t)SL * H * D * 2;
-            GemmArgs g = G_(e->embT, D, cv + off, D, M, nVn * H, D);
-            g.A_lo = emb_lo; g.B_lo = cv + whalf + off;
-            g.bias = e->cv_b + (size_t)SL * H; g.out_f32 = (float*)e->Vnat; g.ldo = nVn * H;
-            KCHK(e, egemm(e, 1, g, s));
-        }
-        if (TL - SL - 1 > 0) {
+        {   // V token-major of layers >= SL from V^T, K^T of layers > SL from K token-major (see feat_to_tok_kernel)
+            const int nVn = TL - SL, R = nVn * H;
+            hipLaunchKernelGGL(feat_to_tok_kernel, dim3((R + 31) / 32, (N + 31) / 32, B), dim3(32, 8), 0, s,
+                               (const float*)e->Vt + (size_t)SL * H * ldv, ldv, e->Npad, (float*)e->Vnat, R, N);
             const int nKt = TL - SL - 1;
-            const size_t off = (size_t)(SL + 1) * H * D * 2;
-            GemmArgs g = G_(ck + off, D, e->embT, D, nKt * H, M, D);
-            g.A_lo = ck + whalf + off; g.B_lo = emb_lo;
-            g.bias = e->ck_b + (size_t)(SL + 1) * H; g.bias_on_rows = 1; g.out_f32 = (float*)e->Kt; g.ldo = ldv; g.col_div = N; g.col_pad = e->Npad;
-            KCHK(e, egemm(e, 1, g, s));
+            if (nKt > 0)
+                hipLaunchKernelGGL(tok_to_feat_kernel, dim3((nKt * H + 31) / 32, (N + 31) / 32, B), dim3(32, 8), 0, s,
+                                   (const float*)e->Knat + (size_t)(SL + 1) * H, TL * H, (float*)e->Kt, ldv, e->Npad, nKt * H, N);
+            if (hipGetLastError() != hipSuccess) return fail(e, PNP_ERR_HIP, "cross K / V layout kernels failed to launch");
         }
         return PNP_OK;
     }
