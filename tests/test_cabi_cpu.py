@@ -61,3 +61,13 @@ def test_null_engine_calls_return_errors(lib):
     assert lib.pnp_vit_forward(None, None, None, 1, None) != 0
     lib.pnp_last_error.restype = ctypes.c_char_p
     assert lib.pnp_last_error(None) == b"null engine"
+
+
+def test_operator_entry_points_validate_arguments_without_a_gpu(lib):
+    """Argument checks that sit in front of any HIP call: null operands and out-of-range modes are refused (PNP_ERR_ARG = -22)
+    on a box without a GPU too."""
+    lib.pnp_op_gemm_x3a.restype = ctypes.c_int
+    lib.pnp_op_gemm_x3.restype = ctypes.c_int
+    n = None
+    assert lib.pnp_op_gemm_x3a(n, 64, n, n, 64, 8, 64, 64, n, n, 0, n, 64, 0, n, 0, n) == -22
+    assert lib.pnp_op_gemm_x3(n, n, 64, n, n, 64, 8, 64, 64, n, 0, n, 0, n, 0, n, n, 0, 0, 0, 0, n) == -22

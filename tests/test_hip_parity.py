@@ -1034,6 +1034,18 @@ def test_bf16x3_picks_equal_f32_at_blip_large_batch8():
     assert not bad, f"pick sets differ in (image, iteration) pairs {bad}"
     assert np.abs(ax - af).max() < 1e-4
     assert np.abs(_norm01(ax[:, 3:-1]) - _norm01(af[:, 3:-1])).max() < 2e-2
+    # ... and all the way to the label maps: the same post-processing (threshold / upsample / blur / DenseCRF / remap) of the two
+    # aggregated maps may differ only where two channels are a near-tie (measured 0.03-0.15 % of the pixels; bound 0.5 %)
+    e = _engine(cfg, 0, "f32", max_batch=B, max_text_len=32)
+    rgb, _ = synth.synth_images(B, 336, seed=515, noise=4)
+    e.post_reserve(B, B * 336 * 336, 336 * 336, 21, 0)
+    e.post_prepare([(336, 336)] * B, [[([i], 1) for i in range(20)]] * B, [list(range(21))] * B, [True] * B, rgb=_dev(rgb.reshape(-1)))
+    labs = {}
+    for mode, a in (("f32", af), ("bf16x3", ax)):
+        labs[mode] = e.postprocess(_dev(a), 0.15, False, "blur+crf").cpu().numpy()
+        torch.cuda.synchronize()
+    differ = float((labs["f32"] != labs["bf16x3"]).mean())
+    assert differ < 5e-3, differ
 
 
 @pytest.mark.parametrize("n_classes", [150, 187])
