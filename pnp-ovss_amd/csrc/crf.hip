@@ -18,6 +18,8 @@
 
 #include <mutex>
 
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 #include "../../include/pnp_math.h"
@@ -1005,8 +1007,15 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
     // tile + per-pixel slice records; wide rows (150 classes) take fewer pixels per tile to stay inside the CU's 160 KB
     size_t tp = (size_t)(CRF_TP / (groups > 0 ? groups : 1));
     const size_t per_pixel = ((size_t)max_kp + 1 + 20) * sizeof(float);
-    if (tp * per_pixel > 160 * 1024) tp = 160 * 1024 / per_pixel;
     if (groups == 2 && tp > 64) tp = 64;                     // smaller tiles, more resident workgroups: 643 -> 624 us on the paired bench rows
+    // wide rows: keep a tile under ~48 KB so that three workgroups stay resident per CU (the kernel waits on its row gathers;
+    // measured per bench step: COCO-Object K = 81 70 -> 58 ms at 64 pixels, ADE20K K = 2 x 150 348 -> 278 ms at 32 pixels;
+    // below 32 pixels the per-tile overheads win: 295 ms at 16, 389 ms at 8)
+    while (tp > 16 && tp * per_pixel > 48 * 1024) tp >>= 1;
+    if (tp * per_pixel > 158 * 1024) tp = 158 * 1024 / per_pixel;
+#ifdef PNP_DEV
+    if (getenv("PNP_CRF_TP") && (size_t)atoi(getenv("PNP_CRF_TP")) < tp) tp = (size_t)atoi(getenv("PNP_CRF_TP"));
+#endif
     if (tp < 1) return PNP_ERR_ARG;
     const size_t smem = tp * per_pixel;
     if (smem > 64 * 1024) {
