@@ -42,8 +42,27 @@ __device__ __forceinline__ uint64_t sal_key(float v, int idx) {
     return ((uint64_t)u << 32) | (uint32_t)idx;
 }
 
-__global__ __launch_bounds__(256) void drop_step_kernel(const float* __restrict__ G, float* __restrict__ g0,
-                                                        float* __restrict__ agg, uint8_t* __restrict__ dropped,
+// the element-wise half of the step, over the whole (B, T, P^2) array: g0 (first iteration) and the running aggregate take the
+// map with the already-dropped cells zeroed.  Runs before drop_step_kernel of the same iteration (which flags the new picks).
+__global__ __launch_bounds__(256) void drop_accumulate_kernel(const float* __restrict__ G, float* __restrict__ g0,
+                                                              float* __restrict__ agg, const uint8_t* __restrict__ dropped,
+                                                              int iter, int T, int PP) {
+    const int b = blockIdx.y;
+    const uint8_t* dr = dropped + (size_t)b * PP;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < T * PP; i += gridDim.x * 256) {
+        const int p = i % PP;
+        const size_t o = (size_t)b * T * PP + i;
+        const float v = dr[p] ? 0.f : G[o];
+        if (iter == 0) {
+            if (g0) g0[o] = v;
+            agg[o] = v + v;
+        } else {
+            agg[o] += v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void drop_step_kernel(const float* __restrict__ G, uint8_t* __restrict__ dropped,
                                                         int32_t* __restrict__ picks, int iter, int T, int PP,
                                                         int npick, int max_picks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -54,19 +73,16 @@ __global__ __launch_bounds__(256) void drop_step_kernel(const float* __restrict_
     uint8_t* dr = dropped + (size_t)b * PP;
     for (int p = tid; p < PP; p += 256) {
         float s = 0.f;
-        for (int t = 3; t < T - 1; t++) s += Gb[(size_t)t * PP + p];
-        sal[p] = dr[p] ? 0.f : s;
-    }
-    for (int i = tid; i < T * PP; i += 256) {
-        const int p = i % PP;
-        const float v = dr[p] ? 0.f : Gb[i];
-        const size_t o = (size_t)b * T * PP + i;
-        if (iter == 0) {
-            if (g0) g0[o] = v;
-            agg[o] = v + v;
-        } else {
-            agg[o] += v;
+        int t = 3;
+        for (; t + 8 <= T - 1; t += 8) {                         // eight plane loads in flight, summed in order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = Gb[(size_t)(t + u) * PP + p];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
         }
+        for (; t < T - 1; t++) s += Gb[(size_t)t * PP + p];
+        sal[p] = dr[p] ? 0.f : s;
     }
     __syncthreads();
     if (npick <= 0) return;
@@ -335,7 +351,7 @@ __device__ __forceinline__ int reflect_fast(int i, int n) {
 //   axis 0 (vertical):   xs[(32 NT + 2r)][64],     thread = (column c, row group of 8) per sub-tile
 //   axis 1 (horizontal): xs[32][colsP], colsP = 64 NT + 2r rounded up to odd (conflict-free row stride),
 //                        thread = (row, column group of 8) per sub-tile
-__global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
+__global__ __launch_bounds__(1024) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const PostDesc* __restrict__ desc, const double* __restrict__ wts,
                                                         const int32_t* __restrict__ wt_off, int axis, int max_radius, int NT) {
     constexpr int TH = 32, TW = 64;
@@ -352,8 +368,9 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
     const int radius = wt_off[b + 1] - wt_off[b] - 1;
     const float* src = in + d.off + (size_t)k * H * W;
     float* dst = out + d.off + (size_t)k * H * W;
-    const int tid = threadIdx.x;
-    for (int j = tid; j <= radius; j += 256) wl[j] = w[j];
+    const int tid = threadIdx.x, nthr = blockDim.x;                      // 256 threads per sub-tile: NT * 256
+    const int sub = tid >> 8, t = tid & 255;
+    for (int j = tid; j <= radius; j += nthr) wl[j] = w[j];
     const int colsP = (TWe + 2 * radius) | 1;
     for (int tl = blockIdx.x; tl < tiles_x * tiles_y; tl += gridDim.x) {
         const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
@@ -366,23 +383,24 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
             const int x = x0 + c < W ? x0 + c : W - 1;
             // eight independent loads in flight per thread (a one-load-per-iteration loop made the whole kernel
             // wait on global latency: the arithmetic of a tile is ~1 us, its staging was ~20 us)
-            for (int r0 = tid >> 6; r0 < rows; r0 += 32) {
+            const int rp = nthr >> 6;                    // rows staged per pass of the workgroup
+            for (int r0 = tid >> 6; r0 < rows; r0 += 8 * rp) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int r = r0 + 4 * u;
+                    const int r = r0 + rp * u;
                     v[u] = r < rows ? src[(size_t)reflect_fast(y0 - radius + r, H) * W + x] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int r = r0 + 4 * u;
+                    const int r = r0 + rp * u;
                     if (r < rows) xs[r * TW + c] = v[u];
                 }
             }
             __syncthreads();
-            for (int nt = 0; nt < NT; nt++) {
-                const int rg = nt * 4 + (tid >> 6);
-                if (y0 + rg * 8 >= H) break;
+            {
+                const int rg = sub * 4 + (t >> 6);
+                if (y0 + rg * 8 >= H) continue;
                 blur_window8(xs + (size_t)(rg * 8 + radius) * TW + c, TW, wl, radius, acc);
                 if (x0 + c < W) {
 #pragma unroll
@@ -393,26 +411,26 @@ __global__ __launch_bounds__(256) void blur_axis_kernel(const float* __restrict_
         } else {
             // flat (row, column) index so all 256 threads load, eight independent loads in flight each
             const int total = TH * colsP;
-            for (int i0 = tid; i0 < total; i0 += 8 * 256) {
+            for (int i0 = tid; i0 < total; i0 += 8 * nthr) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int i = i0 + u * 256;
+                    const int i = i0 + u * nthr;
                     const int r = i / colsP, c = i - r * colsP;
                     const int y = y0 + r < H ? y0 + r : H - 1;
                     v[u] = i < total ? src[(size_t)y * W + reflect_fast(x0 - radius + c, W)] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const int i = i0 + u * 256;
+                    const int i = i0 + u * nthr;
                     if (i < total) xs[i] = v[u];
                 }
             }
             __syncthreads();
-            const int rr = tid & 31;
-            for (int nt = 0; nt < NT; nt++) {
-                const int cg = nt * 8 + (tid >> 5);
-                if (x0 + cg * 8 >= W) break;
+            const int rr = t & 31;
+            {
+                const int cg = sub * 8 + (t >> 5);
+                if (x0 + cg * 8 >= W) continue;
                 blur_window8(xs + (size_t)rr * colsP + radius + cg * 8, 1, wl, radius, acc);
                 if (y0 + rr < H) {
                     float* o = dst + (size_t)(y0 + rr) * W + x0 + cg * 8;
@@ -557,6 +575,88 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ ma
     }
 }
 
+// The same unary for wide rows (K >= 32: the 59 / 80 / 150-class prompts).  Parking a pixel's K exponentials in LDS leaves
+// 256 / (K + 1) KB-sized tiles -- one 4-wave workgroup per CU at K = 150, every thread walking 150 channel planes with a
+// handful of loads in flight: 10.5 ms per launch at ADE20K size, latency-bound.  Here nothing is parked: a wave owns 64
+// pixels, reads the planes three times (maximum; sum of exponentials; the exponentials again for p = e / s -- the same
+// values, pnp_expf is a pure function), eight loads in flight per pass, and only a 64 x 32-float transpose tile per wave goes
+// through LDS so the pixel-major rows leave as 16-byte chunks, eight chunks (128 B) of a row at a time.  8.4 KB of LDS per
+// wave: four waves per SIMD with eight loads in flight each.  Sums and maxima are the sequential per-pixel ones of unary_kernel.
+__global__ __launch_bounds__(256) void unary_wide_kernel(const float* __restrict__ maps, const PostDesc* __restrict__ desc,
+                                                         float* __restrict__ unary, int group) {
+    __shared__ float tiles[4][64][33];
+    const int b = blockIdx.y;
+    const int n = desc[b].H * desc[b].W, K = desc[b].K, R4 = desc[b].Kp >> 2, G = desc[b].G;
+    const int f0 = group * desc[b].Kg, f1 = f0 + K;
+    const int c_lo = f0 >> 2, c_hi = group == G - 1 ? R4 : (f1 + 3) >> 2;
+    const float* m = maps + desc[b].off;
+    f32x4* u4 = reinterpret_cast<f32x4*>(unary + desc[b].qoff);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float (*tile)[33] = tiles[wave];
+    for (int p0 = (blockIdx.x * 4 + wave) * 64; p0 < n; p0 += gridDim.x * 256) {
+        const int i = p0 + lane < n ? p0 + lane : n - 1;                  // lanes past the end redo the last pixel, store nothing
+        const float* mi = m + i;
+        float mx = mi[0];
+        int k = 1;
+        for (; k + 8 <= K; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = mi[(size_t)(k + u) * n];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (v[u] > mx || v[u] != v[u]) mx = v[u];
+        }
+        for (; k < K; k++) {
+            const float v = mi[(size_t)k * n];
+            if (v > mx || v != v) mx = v;
+        }
+        float s = 0.f;
+        for (k = 0; k + 8 <= K; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = mi[(size_t)(k + u) * n];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s = __fadd_rn(s, pnp_expf(__fsub_rn(v[u], mx)));
+        }
+        for (; k < K; k++) s = __fadd_rn(s, pnp_expf(__fsub_rn(mi[(size_t)k * n], mx)));
+        // blocks of 8 chunks = 32 floats of the row
+        for (int cb = c_lo; cb < c_hi; cb += 8) {
+            const int fb = 4 * cb;                                         // first row float of the block
+            const int ka = (fb > f0 ? fb : f0) - f0, kb = (fb + 32 < f1 ? fb + 32 : f1) - f0;   // channels [ka, kb) fall in it
+            for (k = ka; k < kb; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = k + u < kb ? mi[(size_t)(k + u) * n] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    if (k + u < kb) {
+                        float p = __fdiv_rn(pnp_expf(__fsub_rn(v[u], mx)), s);
+                        if (p < 1e-5f) p = 1e-5f;
+                        else if (p > 1.0f) p = 1.0f;
+                        tile[lane][f0 + k + u - fb] = -pnp_logf(p);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int ncb = c_hi - cb < 8 ? c_hi - cb : 8;
+            for (int item = lane; item < 64 * ncb; item += 64) {
+                const int pl = item / ncb, c = item - pl * ncb;
+                if (p0 + pl >= n) continue;
+                f32x4* dst = u4 + (size_t)(p0 + pl) * R4 + cb + c;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (4 * (cb + c) < f0) v = *dst;                           // the previous group's floats of a shared chunk
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int f = fb + 4 * c + j;
+                    if (f >= f0) v[j] = f < f1 ? tile[pl][f - fb] : 0.f;
+                }
+                *dst = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // argmax over channels.  pixel_major: Q[n][Kp] (CRF marginals, rows padded to Kp) else maps[K][n].
 // np.argmax semantics: first maximum, NaN counts as maximum.
 __global__ void argmax_kernel(const float* __restrict__ q, const PostDesc* __restrict__ desc, const int32_t* __restrict__ lut,
@@ -638,8 +738,10 @@ int gradcam_gather(const float* P, const float* dP, const int64_t* mask, int ld_
 int drop_step(const float* G, float* g0, float* agg, uint8_t* dropped, int32_t* picks, int iter, int B, int T, int PP,
               int npick, int max_picks, hipStream_t s) {
     if (PP * sizeof(float) > 48 * 1024) return PNP_ERR_ARG;
-    hipLaunchKernelGGL(drop_step_kernel, dim3(B), dim3(256), PP * sizeof(float), s, G, g0, agg, dropped, picks, iter, T,
-                       PP, npick, max_picks);
+    const int nb = (T * PP + 1023) / 1024 < 256 ? (T * PP + 1023) / 1024 : 256;
+    hipLaunchKernelGGL(drop_accumulate_kernel, dim3(nb, B), dim3(256), 0, s, G, g0, agg, dropped, iter, T, PP);
+    hipLaunchKernelGGL(drop_step_kernel, dim3(B), dim3(256), PP * sizeof(float), s, G, dropped, picks, iter, T, PP, npick,
+                       max_picks);
     return ok();
 }
 
@@ -711,8 +813,8 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
     }
     const int tiles0 = ((maxW + 63) / 64) * ((maxH + 32 * nt0 - 1) / (32 * nt0));
     const int tiles1 = ((maxW + 64 * nt1 - 1) / (64 * nt1)) * ((maxH + 31) / 32);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles0, Kmax, B), dim3(256), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius, nt0);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles1, Kmax, B), dim3(256), lds1, s, tmp, out, desc, wts, wt_off, 1, max_radius, nt1);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles0, Kmax, B), dim3(256 * nt0), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius, nt0);
+    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles1, Kmax, B), dim3(256 * nt1), lds1, s, tmp, out, desc, wts, wt_off, 1, max_radius, nt1);
     return ok();
 }
 
@@ -725,6 +827,11 @@ int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B
             hipSuccess)
             return PNP_ERR_HIP;
         attr_set = true;
+    }
+    if (max_kp >= 32) {                                                    // wide rows: nothing parked in LDS
+        const int nbw = (maxHW + 255) / 256 < 2048 ? (maxHW + 255) / 256 : 2048;
+        hipLaunchKernelGGL(unary_wide_kernel, dim3(nbw, B), dim3(256), 0, s, maps, desc, unary, group);
+        return ok();
     }
     hipLaunchKernelGGL(unary_kernel, dim3(nb, B), dim3(256), smem, s, maps, desc, unary, group);
     return ok();
