@@ -576,17 +576,21 @@ __global__ __launch_bounds__(256) void crf_blur4x2_kernel(const CrfLattice L, co
     }
 }
 
-// Fused tail of a mean-field iteration for a tile of 256 pixels:
+// Fused tail of a mean-field iteration for a tile of up to 256 pixels:
 //   t = -U - (-w_g * norm_g * slice_g) - (-w_b * norm_b * slice_b)   (both lattices already blurred)
 //   Q = exp(t - max_k t) / sum_k          (per pixel, staged through LDS so global I/O stays 16-B wide)
 // pairwise == 0: Q = softmax(-U) (the initial marginals).
+// A tile is a TW x TH BLOCK of pixels, not a run of a raster line: the simplex vertices of a pixel are shared with its
+// neighbours in both directions (Gaussian cells are 3 px wide, lattice points are numbered along a Z-order curve), so a block
+// touches about half the distinct value rows of a strip of the same size and the slice gathers hit L1 / L2 accordingly.
 constexpr int CRF_TP = 256;
-__global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, const CrfLattice Lb, const PostDesc* __restrict__ imgs,
+__host__ __device__ inline int crf_tile_w(int tp) { return tp >= 128 ? 16 : tp >= 32 ? 8 : 4; }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void crf_update_kernel(const CrfLattice Lg, const CrfLattice Lb, const PostDesc* __restrict__ imgs,
                                                          const float* __restrict__ vg, const float* __restrict__ vb,
                                                          const float* __restrict__ norm_g, const float* __restrict__ norm_b,
                                                          const float* __restrict__ unary, float* __restrict__ Q, float w_g,
                                                          float w_b, float alpha_g, float alpha_b, int pairwise, int img0,
-                                                         int nimg, int tp_cap, const CrfLabelOut lout) {
+                                                         int nimg, int tp_cap, int tile_w, const CrfLabelOut lout) {
     extern __shared__ __attribute__((aligned(16))) float tile[];        // [TP][Kp + 1], then the slice records [TP][20]
     // XCD-affine sweep like the splat / blur kernels: the slice gathers of an image hit the value rows
     // its XCD has just blurred
@@ -595,12 +599,14 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
     int b, part, parts;
     for (int wi = 0; xcd_work(wi, xcd, img0, nimg, b, part, parts); wi++) {
         const PostDesc im = imgs[b];
-        const int npix = im.H * im.W;
-        const int pfirst = (int)((long)npix * part / parts), n = (int)((long)npix * (part + 1) / parts);
         const int K = im.K, Kp = im.Kp, K4 = Kp >> 2, ldt = Kp + 1;
         f32x4* Q4 = reinterpret_cast<f32x4*>(Q + im.qoff);
         const int lo_g = pairwise ? Lg.idbase[b] : 0, lo_b = pairwise ? Lb.idbase[b] : 0;
-        const int TP = CRF_TP / im.G < tp_cap ? CRF_TP / im.G : tp_cap; // pixels per tile: one softmax thread per (pixel, group)
+        const int TPe = CRF_TP / im.G < tp_cap ? CRF_TP / im.G : tp_cap; // one softmax thread per (pixel, group)
+        const int TW = tile_w > 0 ? tile_w : crf_tile_w(TPe), TH = TPe / TW, TP = TW * TH;   // TW: a power of two
+        const int tw_shift = __ffs(TW) - 1;
+        const int tiles_x = (im.W + TW - 1) / TW, tiles_y = (im.H + TH - 1) / TH, ntiles = tiles_x * tiles_y;
+        const int tfirst = (int)((long)ntiles * part / parts), tend = (int)((long)ntiles * (part + 1) / parts);
         // rows of the pixel-major arrays and of the lattice value arrays as base + 32-bit byte offset
         const char* const Ub = reinterpret_cast<const char*>(unary + im.qoff);
         const char* const Gb = reinterpret_cast<const char*>(vg + im.voff[0]);
@@ -614,68 +620,83 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
         float* const rec_ng = rec_nb + TP;
         const int q256 = 256 / K4, r256 = 256 - q256 * K4;             // item -> (pixel, chunk) advance without a division
         const int pl0 = tid / K4, c0 = tid - pl0 * K4;
-        for (int p0 = pfirst + slot * TP; p0 < n; p0 += bpx * TP) {
-            const int np = (n - p0) < TP ? (n - p0) : TP;
+        for (int tl = tfirst + slot; tl < tend; tl += bpx) {
+            const int ty = tl / tiles_x, tx = tl - ty * tiles_x;
+            const int x0 = tx * TW, y0 = ty * TH;
+            // slots of an edge tile that fall outside the image redo its last column / row (branch-free main loop) and
+            // store nothing
+            auto pixel_of = [&](int pl) {
+                const int x = x0 + (pl & (TW - 1)), y = y0 + (pl >> tw_shift);
+                return (y < im.H ? y : im.H - 1) * im.W + (x < im.W ? x : im.W - 1);
+            };
+            auto inside = [&](int pl) { return x0 + (pl & (TW - 1)) < im.W && y0 + (pl >> tw_shift) < im.H; };
             // the tile's per-pixel slice records -- 6 + 3 image-local lattice ids and barycentric weights, two normalisers --
             // are staged once through LDS (coalesced loads) instead of being fetched by every channel-chunk lane of the
             // pixel: 10 vector-memory instructions per (pixel, chunk) item instead of 30 (the kernel is issue-bound there)
             if (pairwise) {
-                const size_t gp0 = (size_t)im.pix0 + p0;
-                for (int i = tid; i < np * 6; i += 256) {
-                    rec_ob[i] = Lb.offset[gp0 * 6 + i] - lo_b;
-                    rec_wb[i] = Lb.bary[gp0 * 6 + i];
+                for (int i = tid; i < TP * 6; i += 256) {
+                    const int pl = i / 6;
+                    const size_t g = ((size_t)im.pix0 + pixel_of(pl)) * 6 + (i - pl * 6);
+                    rec_ob[i] = Lb.offset[g] - lo_b;
+                    rec_wb[i] = Lb.bary[g];
                 }
-                for (int i = tid; i < np * 3; i += 256) {
-                    rec_og[i] = Lg.offset[gp0 * 3 + i] - lo_g;
-                    rec_wg[i] = Lg.bary[gp0 * 3 + i];
+                for (int i = tid; i < TP * 3; i += 256) {
+                    const int pl = i / 3;
+                    const size_t g = ((size_t)im.pix0 + pixel_of(pl)) * 3 + (i - pl * 3);
+                    rec_og[i] = Lg.offset[g] - lo_g;
+                    rec_wg[i] = Lg.bary[g];
                 }
-                for (int i = tid; i < np; i += 256) {
-                    rec_nb[i] = norm_b[gp0 + i];
-                    rec_ng[i] = norm_g[gp0 + i];
+                for (int pl = tid; pl < TP; pl += 256) {
+                    const size_t g = (size_t)im.pix0 + pixel_of(pl);
+                    rec_nb[pl] = norm_b[g];
+                    rec_ng[pl] = norm_g[g];
                 }
                 __syncthreads();
             }
             {
                 int pl = pl0, c = c0;
-                for (int item = tid; item < np * K4; item += 256) {
-                    const uint32_t cofs = (uint32_t)c * 16u;
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(Ub + (__umul24((uint32_t)(p0 + pl), rowb) + cofs));
-                    f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
-                    if (pairwise) {
-                        f32x4 vg3[3], vb6[6];
+                for (int item = tid; item < TP * K4; item += 256) {
+                    const int px = pixel_of(pl);
+                    {
+                        const uint32_t cofs = (uint32_t)c * 16u;
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(Ub + (__umul24((uint32_t)px, rowb) + cofs));
+                        f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
+                        if (pairwise) {
+                            f32x4 vg3[3], vb6[6];
 #pragma unroll
-                        for (int v = 0; v < 3; v++)
-                            vg3[v] = *reinterpret_cast<const f32x4*>(Gb + (__umul24((uint32_t)rec_og[pl * 3 + v], rowb) + cofs));
+                            for (int v = 0; v < 3; v++)
+                                vg3[v] = *reinterpret_cast<const f32x4*>(Gb + (__umul24((uint32_t)rec_og[pl * 3 + v], rowb) + cofs));
 #pragma unroll
-                        for (int v = 0; v < 6; v++)
-                            vb6[v] = *reinterpret_cast<const f32x4*>(Bb + (__umul24((uint32_t)rec_ob[pl * 6 + v], rowb) + cofs));
-                        {
-                            f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                            for (int v = 0; v < 6; v++)
+                                vb6[v] = *reinterpret_cast<const f32x4*>(Bb + (__umul24((uint32_t)rec_ob[pl * 6 + v], rowb) + cofs));
+                            {
+                                f32x4 out = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int v = 0; v < 3; v++) {
-                                const float wv = rec_wg[pl * 3 + v];
+                                for (int v = 0; v < 3; v++) {
+                                    const float wv = rec_wg[pl * 3 + v];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, vg3[v][i]), alpha_g));
+                                    for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, vg3[v][i]), alpha_g));
+                                }
+                                const float nr = rec_ng[pl];
+#pragma unroll
+                                for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_g, __fmul_rn(out[i], nr)));
                             }
-                            const float nr = rec_ng[pl];
+                            {
+                                f32x4 out = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                            for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_g, __fmul_rn(out[i], nr)));
-                        }
-                        {
-                            f32x4 out = {0.f, 0.f, 0.f, 0.f};
+                                for (int v = 0; v < 6; v++) {
+                                    const float wv = rec_wb[pl * 6 + v];
 #pragma unroll
-                            for (int v = 0; v < 6; v++) {
-                                const float wv = rec_wb[pl * 6 + v];
+                                    for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, vb6[v][i]), alpha_b));
+                                }
+                                const float nr = rec_nb[pl];
 #pragma unroll
-                                for (int i = 0; i < 4; i++) out[i] = __fadd_rn(out[i], __fmul_rn(__fmul_rn(wv, vb6[v][i]), alpha_b));
+                                for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_b, __fmul_rn(out[i], nr)));
                             }
-                            const float nr = rec_nb[pl];
-#pragma unroll
-                            for (int i = 0; i < 4; i++) t[i] = __fsub_rn(t[i], __fmul_rn(-w_b, __fmul_rn(out[i], nr)));
                         }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) tile[pl * ldt + 4 * c + i] = t[i];
                     pl += q256;
                     c += r256;
                     if (c >= K4) {
@@ -685,43 +706,48 @@ __global__ __launch_bounds__(256) void crf_update_kernel(const CrfLattice Lg, co
                 }
             }
             __syncthreads();
-            if (tid < np * im.G) {                                      // one softmax per (pixel, channel group)
-                const int grp = tid / np, px = tid - grp * np;
-                float* row = tile + px * ldt + grp * im.Kg;
-                float m = row[0];
-                for (int k = 1; k < K; k++) {
-                    const float v = row[k];
-                    if (v > m || v != v) m = v;
-                }
-                float s = 0.f;
-                for (int k = 0; k < K; k++) {
-                    const float e = pnp_expf(__fsub_rn(row[k], m));
-                    row[k] = e;
-                    s = __fadd_rn(s, e);
-                }
-                for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
-                if (lout.lab[grp]) {
-                    // last iteration: the label of this (pixel, group) straight from the marginals in LDS -- first maximum,
-                    // NaN counts as maximum (np.argmax, as argmax_kernel reads them back from memory) -- through the LUT
-                    int best = 0;
-                    float bv = row[0];
+            if (tid < TP * im.G) {                                      // one softmax per (pixel, channel group)
+                const int grp = tid / TP, px = tid - grp * TP;
+                const int p = pixel_of(px);
+                {
+                    float* row = tile + px * ldt + grp * im.Kg;
+                    float m = row[0];
                     for (int k = 1; k < K; k++) {
                         const float v = row[k];
-                        if (bv == bv && (v > bv || v != v)) {
-                            best = k;
-                            bv = v;
-                        }
+                        if (v > m || v != v) m = v;
                     }
-                    lout.lab[grp][lout.label_off[b] + p0 + px] = (uint8_t)lout.lut[b * lout.lut_stride + best];
+                    float s = 0.f;
+                    for (int k = 0; k < K; k++) {
+                        const float e = pnp_expf(__fsub_rn(row[k], m));
+                        row[k] = e;
+                        s = __fadd_rn(s, e);
+                    }
+                    for (int k = 0; k < K; k++) row[k] = __fdiv_rn(row[k], s);
+                    if (lout.lab[grp]) {
+                        // last iteration: the label of this (pixel, group) straight from the marginals in LDS -- first maximum,
+                        // NaN counts as maximum (np.argmax, as argmax_kernel reads them back from memory) -- through the LUT
+                        int best = 0;
+                        float bv = row[0];
+                        for (int k = 1; k < K; k++) {
+                            const float v = row[k];
+                            if (bv == bv && (v > bv || v != v)) {
+                                best = k;
+                                bv = v;
+                            }
+                        }
+                        if (inside(px)) lout.lab[grp][lout.label_off[b] + p] = (uint8_t)lout.lut[b * lout.lut_stride + best];
+                    }
+                    if (grp == im.G - 1)                                // pad floats behind the last group stay zero
+                        for (int k = im.G * im.Kg; k < Kp; k++) tile[px * ldt + k] = 0.f;
                 }
-                if (grp == im.G - 1)                                    // pad floats behind the last group stay zero
-                    for (int k = im.G * im.Kg; k < Kp; k++) tile[px * ldt + k] = 0.f;
             }
             __syncthreads();
-            for (int item = tid; item < np * K4; item += 256) {
+            for (int item = tid; item < TP * K4; item += 256) {
                 const int pl = item / K4, c = item - pl * K4;
-                const float* r = tile + pl * ldt + 4 * c;
-                Q4[(size_t)(p0 + pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
+                if (inside(pl)) {
+                    const float* r = tile + pl * ldt + 4 * c;
+                    Q4[(size_t)pixel_of(pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
+                }
             }
             __syncthreads();
         }
@@ -1013,10 +1039,12 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
     // below 32 pixels the per-tile overheads win: 295 ms at 16, 389 ms at 8)
     while (tp > 16 && tp * per_pixel > 48 * 1024) tp >>= 1;
     if (tp * per_pixel > 158 * 1024) tp = 158 * 1024 / per_pixel;
+    int tile_w = 0;                                          // 0: crf_tile_w(pixels per tile)
 #ifdef PNP_DEV
     if (getenv("PNP_CRF_TP") && (size_t)atoi(getenv("PNP_CRF_TP")) < tp) tp = (size_t)atoi(getenv("PNP_CRF_TP"));
+    if (getenv("PNP_CRF_TW")) tile_w = atoi(getenv("PNP_CRF_TW"));   // a power of two <= tp (tp: the whole strip, as before)
 #endif
-    if (tp < 1) return PNP_ERR_ARG;
+    if (tp < 4) return PNP_ERR_ARG;
     const size_t smem = tp * per_pixel;
     if (smem > 64 * 1024) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(crf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1042,7 +1070,7 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
         }
     }
     hipLaunchKernelGGL(crf_update_kernel, dim3(nbu), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
-                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp, labels);
+                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp, tile_w, labels);
     return ok();
 }
 

@@ -18,7 +18,8 @@ from pnp_ovss import config as C, synth, hip
 from pnp_ovss.hip import Engine
 
 if os.environ.get("PNP_DEV_LIB"):                          # DEV build: the PNP_CRF_* knobs of csrc/crf.hip
-    hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), "libpnp_hip_dev.so")
+    _name = os.environ["PNP_DEV_LIB"] if os.environ["PNP_DEV_LIB"].endswith(".so") else "libpnp_hip_dev.so"
+    hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), _name)
 
 B, IMG = 35, 336
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
