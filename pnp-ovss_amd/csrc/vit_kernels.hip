@@ -414,11 +414,30 @@ __global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict_
     }
 }
 
+#ifdef PNP_DEV
+// DEV diagnostics: per-(wave, key tile) issue-time clock stamps of workgroup (0, 0, 0) of the split-bf16 attention
+// (tools/attn_x3_probe.py --stamps): [wave][tile][6] = loop top, barrier passed, DMA issued, S issued, softmax done, P.V issued
+__device__ unsigned long long* g_attn_stamps = nullptr;
+extern "C" int pnp_dev_attn_stamps(unsigned long long* d_buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &d_buf, sizeof(d_buf)) == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+#define PNP_ATTN_STAMP(k)                                                                                       \
+    do {                                                                                                        \
+        if (stamps && lane == 0) {                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+            stamps[((size_t)wave * ntiles + t) * 6 + (k)] = __builtin_readcyclecounter();                       \
+            __builtin_amdgcn_sched_barrier(0);                                                                  \
+        }                                                                                                       \
+    } while (0)
+#else
+#define PNP_ATTN_STAMP(k) do {} while (0)
+#endif
+
 // Split-bf16 ("bf16x3") form of the kernel above for compute mode 2: q, k, v arrive as (hi, lo) bf16 pairs (the fused
 // q|k|v rows of the split-output GEMM), both products run as three bf16 MFMA passes -- S = K_hi.Q_hi + K_hi.Q_lo + K_lo.Q_hi,
 // O += V_hi.P_hi + V_hi.P_lo + V_lo.P_hi with P split after the exp2 -- and the context leaves as a (hi, lo) pair for the
 // proj GEMM.  Same tiling, ring and softmax; the ring slot holds four tiles (K_hi, V_hi, K_lo, V_lo).
-__global__ __launch_bounds__(512) void vit_attn32_x3_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ qk_lo, int ld_qk, int D,
+__global__ __launch_bounds__(768) void vit_attn32_x3_kernel(const bf16* __restrict__ qk, const bf16* __restrict__ qk_lo, int ld_qk, int D,
                                                             const bf16* __restrict__ vt, const bf16* __restrict__ vt_lo, int ld_vt,
                                                             bf16* __restrict__ ctx, bf16* __restrict__ ctx_lo, int N, float scale, int nqw) {
     constexpr int ROWB = 128, TILE = 64 * ROWB;         // K tile [64 keys][64 d], V tile [64 keys][64 d] (transposed on the read)
@@ -444,20 +463,34 @@ __global__ __launch_bounds__(512) void vit_attn32_x3_kernel(const bf16* __restri
         }
     }
     const size_t koff = (row0 * ld_qk + D + h * 64) * 2, voff = (row0 * ld_vt + h * 64) * 2;
-    const char* kb[2] = {reinterpret_cast<const char*>(qk) + koff, reinterpret_cast<const char*>(qk_lo) + koff};
-    const char* vb[2] = {reinterpret_cast<const char*>(vt) + voff, reinterpret_cast<const char*>(vt_lo) + voff};
+    // A DMA piece = 8 key rows x 128 B of one of the four operand tiles (pieces 0-7 K_hi, 8-15 V_hi, 16-23 K_lo, 24-31 V_lo of
+    // key tile t; wave w owns pieces w, w + nwaves, ...).  Its address is a UNIFORM 64-bit base (operand, first row of the
+    // piece: scalar registers) + a 32-bit lane offset (row within the piece, swizzled 16-byte chunk).  The four operand bases
+    // are formed by integer masks from one base and three uniform differences -- never by indexing or selecting pointers:
+    // hipcc keeps such pointers (the `kb[2]` / `vb[2]` arrays this kernel had) in scratch memory and loads the selected one per
+    // piece, and that scratch load then waits -- vmcnt is one in-order counter -- for every DMA piece issued before it: ~700
+    // cycles per piece, 3600 of the 9500 cycles a key tile took (tools/attn_x3_probe.py --dev --stamps): 190 -> 149 us at 442
+    // tokens, 758 -> 606 us at 2305.  Rows past N - 1 (ragged last tile) re-read row N - 1: their scores are masked, their V
+    // rows multiply exact zeros and must be finite.
+    const uint64_t k0 = reinterpret_cast<uint64_t>(qk) + koff;
+    const uint64_t d_klo = reinterpret_cast<uint64_t>(qk_lo) + koff - k0;
+    const uint64_t d_v = reinterpret_cast<uint64_t>(vt) + voff - k0;
+    const uint64_t d_vlo = reinterpret_cast<uint64_t>(vt_lo) + voff - k0;
     const int prow = lane >> 3, pc = lane & 7;
+    const uint32_t sc_even = (uint32_t)(pc ^ ((prow >> 1) & 7)) << 4, sc_odd = (uint32_t)(pc ^ ((4 + (prow >> 1)) & 7)) << 4;
     auto issue_tile = [&](int t) {
-        char* dst = ring[t & 1];
-        for (int p = wave; p < 32; p += nwaves) {       // pieces 0-7 K_hi, 8-15 V_hi, 16-23 K_lo, 24-31 V_lo
-            const int row = (p & 7) * 8 + prow;
-            const int sc = pc ^ ((row >> 1) & 7);
-            int key = t * 64 + row;
-            key = key < N ? key : N - 1;
-            const int part = p >> 4;
-            const char* src = (p & 8) ? vb[part] + (size_t)key * ld_vt * 2 + sc * 16 : kb[part] + (size_t)key * ld_qk * 2 + sc * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+        for (int p = wave; p < 32; p += nwaves) {
+            const uint64_t m_v = 0ull - (uint64_t)((p >> 3) & 1), m_lo = 0ull - (uint64_t)(p >> 4);
+            const uint64_t d = (m_v & m_lo & d_vlo) | (m_v & ~m_lo & d_v) | (~m_v & m_lo & d_klo);
+            const uint32_t ld2 = ((uint32_t)ld_qk + ((uint32_t)m_v & (uint32_t)(ld_vt - ld_qk))) * 2u;
+            int rs = t * 64 + (p & 7) * 8;
+            rs = rs < N - 1 ? rs : N - 1;
+            const char* const sbase = reinterpret_cast<const char*>(k0 + d + (uint64_t)((uint32_t)rs * ld2));
+            int lr = rs + prow;
+            lr = (lr < N ? lr : N - 1) - rs;
+            const uint32_t loff = (uint32_t)lr * ld2 + ((p & 1) ? sc_odd : sc_even);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + loff),
+                                             (__attribute__((address_space(3))) void*)(ring[t & 1] + p * 1024), 16, 0, 0);
         }
     };
 
@@ -471,11 +504,17 @@ __global__ __launch_bounds__(512) void vit_attn32_x3_kernel(const bf16* __restri
     const int sw = (l32 >> 1) & 7;
     const int ntiles = (N + 63) / 64;
 
+#ifdef PNP_DEV
+    unsigned long long* const stamps = (blockIdx.x | blockIdx.y | blockIdx.z) == 0 ? g_attn_stamps : nullptr;
+#endif
     issue_tile(0);
     for (int t = 0; t < ntiles; t++) {
+        PNP_ATTN_STAMP(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        PNP_ATTN_STAMP(1);
         if (t + 1 < ntiles) issue_tile(t + 1);
+        PNP_ATTN_STAMP(2);
         const char* Ks = ring[t & 1];
         const char* Vs = Ks + TILE;
         const char* Kl = Ks + 2 * TILE;
@@ -496,6 +535,7 @@ __global__ __launch_bounds__(512) void vit_attn32_x3_kernel(const bf16* __restri
                 s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, fq[ks], s[kt], 0, 0, 0);
             }
         }
+        PNP_ATTN_STAMP(3);
         if (t == ntiles - 1 && (N & 63)) {
 #pragma unroll
             for (int kt = 0; kt < 2; kt++)
@@ -530,6 +570,7 @@ __global__ __launch_bounds__(512) void vit_attn32_x3_kernel(const bf16* __restri
                 fp[kt * 2 + (e >> 3)][e & 7] = ph;
                 fpl[kt * 2 + (e >> 3)][e & 7] = (bf16)(p - (float)ph);
             }
+        PNP_ATTN_STAMP(4);
         const int grp_d = ((lane >> 4) & 1) * 16, tq = (lane >> 2) & 3, tp = lane & 3;
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -555,6 +596,7 @@ __global__ __launch_bounds__(512) void vit_attn32_x3_kernel(const bf16* __restri
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[0], fpl[j], o[dt], 0, 0, 0);
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fv[0], fp[j], o[dt], 0, 0, 0);
             }
+        PNP_ATTN_STAMP(5);
     }
     l_run += __shfl_xor(l_run, 32, 64);
     if (q_valid) {
@@ -602,7 +644,13 @@ int vit_attention_x3(const void* qkv_hi, const void* qkv_lo, int ld_qk, int D, v
                      float scale, hipStream_t s) {
     if (D != H * 64 || !qkv_hi || !qkv_lo || !ctx_hi || !ctx_lo) return PNP_ERR_ARG;
     const int nqw = (N + 31) / 32;
-    const int max_wpb = 8;
+    // one workgroup per CU (157 registers: 12 wave slots, two 7-wave workgroups do not fit and smaller ones lose more to the
+    // per-tile hand-over than they win): long sequences take up to 12 waves per workgroup (-3 % at 2305 tokens), 442 tokens
+    // are 14 waves = two workgroups of 7
+    int max_wpb = nqw > 24 ? 12 : 8;
+#ifdef PNP_DEV
+    if (getenv("PNP_ATTN_WPB")) max_wpb = atoi(getenv("PNP_ATTN_WPB"));   // <= 12 (launch bound 768 threads)
+#endif
     const int nblk = (nqw + max_wpb - 1) / max_wpb, wpb = (nqw + nblk - 1) / nblk;
     const bf16 *qh = (const bf16*)qkv_hi, *ql = (const bf16*)qkv_lo;
     hipLaunchKernelGGL(vit_attn32_x3_kernel, dim3(nblk, H, B), dim3(wpb * 64), 0, s, qh, ql, ld_qk, D, qh + 2 * D, ql + 2 * D, ld_qk,

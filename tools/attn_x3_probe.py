@@ -1,5 +1,7 @@
 """Split-bf16 ViT attention at the bench shapes: back-to-back launch time and error against float64 attention of the original
-fp32 q, k, v.  `--dev` uses the DEV library, where PNP_ATTN_OLD=1 selects the un-pipelined kernel for comparison."""
+fp32 q, k, v.  `--dev` uses the DEV library; `--dev --stamps` prints the issue-time clock stamps of workgroup (0, 0, 0):
+per wave and key tile the cycles spent waiting for the tile (DMA + barrier), issuing the next tile's DMA, in the K.Q^T
+products, in the softmax and in the P.V products."""
 import os
 import sys
 import time
@@ -12,6 +14,8 @@ from pnp_ovss import hip
 
 if "--dev" in sys.argv:
     hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), "libpnp_hip_dev.so")
+if "--lib" in sys.argv:                                     # a named library variant next to the product one (A/B runs)
+    hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
 lib = hip.load_library()
 
 
@@ -43,6 +47,38 @@ def run(B, H, N):
     fl = 4.0 * N * N * 64 * H * B
     print(f"B={B} H={H} N={N}: {dt * 1e6:7.1f} us  algorithmic {fl / dt / 1e12:6.0f} TF  issued {3 * fl / dt / 1e12:6.0f} TF  relerr {err:.1e}", flush=True)
 
+
+if "--stamps" in sys.argv:
+    import ctypes as C
+    import numpy as np
+    B, H, N = (8, 16, 2305) if "--all" in sys.argv else (35, 16, 442)
+    D = H * 64
+    nt, nw = (N + 63) // 64, 8
+    buf = torch.zeros(nw * nt * 6, dtype=torch.int64, device="cuda")
+    lib.pnp_dev_attn_stamps.argtypes = [C.c_void_p]
+    assert lib.pnp_dev_attn_stamps(buf.data_ptr()) == 0
+    torch.manual_seed(0)
+    qkv = torch.randn(B * N, 3 * D, device="cuda")
+    hi = torch.empty(qkv.shape, device="cuda", dtype=torch.bfloat16)
+    lo = torch.empty_like(hi)
+    lib.pnp_op_split(qkv.data_ptr(), hi.data_ptr(), lo.data_ptr(), qkv.numel(), None)
+    ch = torch.empty(B * N, D, device="cuda", dtype=torch.bfloat16)
+    cl = torch.empty_like(ch)
+    for _ in range(3):
+        lib.pnp_op_vit_attention_x3(hi.data_ptr(), lo.data_ptr(), 3 * D, D, ch.data_ptr(), cl.data_ptr(), B, H, N, 0.125, None)
+    torch.cuda.synchronize()
+    st = buf.cpu().numpy().reshape(nw, nt, 6)
+    names = ["wait tile", "issue DMA", "K.Q^T", "softmax", "P.V", "loop"]
+    for w in range(nw):
+        if st[w].max() == 0:
+            continue
+        d = np.diff(st[w], axis=1)                       # [tile][5]
+        loop = np.diff(st[w][:, 0])
+        print(f"wave {w}: first stamp {st[w][0, 0] - st[:, 0, 0][st[:, 0, 0] > 0].min():6d}  per tile (median over tiles): "
+              + "  ".join(f"{names[k]} {int(np.median(d[:, k]))}" for k in range(5)) + f"  | tile period {int(np.median(loop)) if len(loop) else 0}")
+    w0 = st[0]
+    print("wave 0 per tile:", [[int(x) for x in np.diff(w0[t])] for t in range(min(nt, 8))])
+    sys.exit(0)
 
 run(35, 16, 442)
 if "--all" in sys.argv:
