@@ -53,7 +53,7 @@ if "--stamps" in sys.argv:
     import numpy as np
     B, H, N = (8, 16, 2305) if "--all" in sys.argv else (35, 16, 442)
     D = H * 64
-    nt, nw = (N + 63) // 64, 8
+    nt, nw = (N + 63) // 64, 12
     buf = torch.zeros(nw * nt * 6, dtype=torch.int64, device="cuda")
     lib.pnp_dev_attn_stamps.argtypes = [C.c_void_p]
     assert lib.pnp_dev_attn_stamps(buf.data_ptr()) == 0
