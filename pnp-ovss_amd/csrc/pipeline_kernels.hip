@@ -326,9 +326,16 @@ __device__ __forceinline__ void blur_window8(const float* __restrict__ ctr, int 
             const int jc = j - jj;                      // current tap distance (may run past 1: predicated)
             if (jc >= 1) {
                 const double wj = wl[jc];
+                // three passes over the eight outputs (sums, products, accumulations) instead of one add-mul-add chain per
+                // output through a single temporary: eight independent fp64 operations between dependent ones
+                double t8[R];
 #pragma unroll
                 for (int i = 0; i < R; i++)             // logical window slot i lives in lo[(i + jj) % R], hi[(i - jj) & 7]
-                    acc[i] = __dadd_rn(acc[i], __dmul_rn(__dadd_rn(lo[(i + jj) % R], hi[(i - jj + R) % R]), wj));
+                    t8[i] = __dadd_rn(lo[(i + jj) % R], hi[(i - jj + R) % R]);
+#pragma unroll
+                for (int i = 0; i < R; i++) t8[i] = __dmul_rn(t8[i], wj);
+#pragma unroll
+                for (int i = 0; i < R; i++) acc[i] = __dadd_rn(acc[i], t8[i]);
                 // shift: lo gains x[o_{R-1} - (jc-1)], hi gains x[o_0 + (jc-1)]
                 lo[jj % R] = (double)ctr[(R - jc) * S];
                 hi[(R - 1 - jj) % R] = (double)ctr[(jc - 1) * S];
