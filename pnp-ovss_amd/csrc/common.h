@@ -149,6 +149,24 @@ __device__ __forceinline__ float gelu_erf_fast(float x) {
     const float e = 1.0f - p * t * __expf(-z * z);           // erf(|x| / sqrt 2)
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
+// the same on two values at once: the polynomial runs on the packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 --
+// two lanes' worth of fp32 per instruction); rcp and exp stay one per value.  Same operations per element as above.
+typedef __attribute__((ext_vector_type(2))) float pnp_f32x2;
+__device__ __forceinline__ pnp_f32x2 gelu_erf_fast2(pnp_f32x2 x) {
+    const pnp_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const pnp_f32x2 z = ax * 0.70710678118654752f;
+    const pnp_f32x2 d = __builtin_elementwise_fma(pnp_f32x2{0.3275911f, 0.3275911f}, z, pnp_f32x2{1.0f, 1.0f});
+    const pnp_f32x2 t = {__frcp_rn(d[0]), __frcp_rn(d[1])};
+    pnp_f32x2 p = __builtin_elementwise_fma(pnp_f32x2{1.061405429f, 1.061405429f}, t, pnp_f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, pnp_f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, pnp_f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, pnp_f32x2{0.254829592f, 0.254829592f});
+    const pnp_f32x2 nz2 = -(z * z);
+    const pnp_f32x2 ex = {__expf(nz2[0]), __expf(nz2[1])};
+    const pnp_f32x2 e = pnp_f32x2{1.0f, 1.0f} - p * t * ex;                 // erf(|x| / sqrt 2)
+    const pnp_f32x2 es = {copysignf(e[0], x[0]), copysignf(e[1], x[1])};
+    return (x * 0.5f) * (pnp_f32x2{1.0f, 1.0f} + es);
+}
 // x * Phi(x) with Phi(x) ~ sigmoid(x (c0 + c1 x^2 + c2 x^4)): minimax fit of the erf form on [-8, 8]
 // (tools/fit_gelu.py), max |error| 2.6e-5 -- 1/150 of a bf16 ulp at 1.0.  Seven VALU + exp2 + rcp; used by
 // the wide GEMM's GELU epilogue only, whose output is stored as bf16.

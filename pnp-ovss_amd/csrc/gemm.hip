@@ -850,9 +850,11 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int gq = 0; gq < 4; gq++)
 #pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const float v = acc[i][j][gq * 4 + e] + bacc[i][gq][e];
-                            acc[i][j][gq * 4 + e] = EPI == WIDE_GELU_SPLIT ? gelu_erf_fast(v) : v;
+                        for (int e = 0; e < 4; e += 2) {
+                            pnp_f32x2 v = {acc[i][j][gq * 4 + e] + bacc[i][gq][e], acc[i][j][gq * 4 + e + 1] + bacc[i][gq][e + 1]};
+                            if constexpr (EPI == WIDE_GELU_SPLIT) v = gelu_erf_fast2(v);
+                            acc[i][j][gq * 4 + e] = v[0];
+                            acc[i][j][gq * 4 + e + 1] = v[1];
                         }
 #pragma unroll
             for (int part = 0; part < 2; part++) {

@@ -16,6 +16,9 @@ DEV = "--dev" in sys.argv
 ONLY = [a for a in sys.argv[1:] if not a.startswith("--")]
 if DEV:
     hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), "libpnp_hip_dev.so")
+if "--lib" in sys.argv:                                     # a named library variant next to the product one (A/B runs)
+    hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
+    ONLY = [a for a in ONLY if not a.endswith(".so")]
 lib = hip.load_library()
 
 
