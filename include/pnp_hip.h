@@ -44,10 +44,12 @@ typedef struct pnp_config {
     int32_t compute_bf16;   /* arithmetic of the dense contractions:
                              *   0  exact fp32 MFMA everywhere (the reference's arithmetic; parity mode)
                              *   1  bf16 storage + bf16 MFMA with fp32 accumulation (throughput mode; ~1 % error on image_embeds)
-                             *   2  split-bf16 ("bf16x3"): ViT Linears and the cross K/V projections on (hi, lo) bf16 operand
-                             *      pairs, three bf16 MFMA passes per product with fp32 accumulation -- fp32-class results
-                             *      (maps within 1e-4 of mode 0, same patch picks) at ~5x the fp32 MFMA rate; attention,
-                             *      text stack, backward and post-processing as in mode 0 */
+                             *   2  split-bf16 ("bf16x3", the benchmarked mode): EVERY dense contraction of the model -- the ViT Linears and
+                             *      the ViT self-attention, the cross K/V projections, the text-side Linears and their analytic
+                             *      backward -- on (hi, lo) bf16 operand pairs, three bf16 MFMA passes per product with fp32
+                             *      accumulation: fp32-class results (maps within 1e-4 of mode 0, same patch picks) at ~5x the
+                             *      fp32 MFMA rate.  Softmax, LayerNorm, the text self- / cross-attention kernels (fp32 operands)
+                             *      and all post-processing are the mode-0 code */
     int32_t device;         /* HIP device ordinal */
 } pnp_config;
 
@@ -300,9 +302,11 @@ int pnp_op_layernorm(const float* d_x, const float* d_w, const float* d_b, float
 int pnp_op_xattn(int32_t bf16, int32_t mode, const void* d_nat, int32_t ld_nat, const void* d_tr, int32_t ld_tr,
                  int32_t n_pad, const void* d_x, int32_t ldx, void* d_out, int32_t ldo, float* d_probs, int32_t n_stride,
                  int32_t B, int32_t L, int32_t N, int32_t heads, void* stream);
-/* Diagnostics: with PNP_GEMM_STAMPS=1 in the environment the wide-tile GEMM records, per workgroup, the
- * shader clock (slots 0-3) and the 100 MHz wall clock (slots 4-7) at kernel start, after the first slab
- * landed, after the main loop and after the epilogue; this copies the last launch's stamps to the host. */
+/* Diagnostics, development builds only (`make DEV=1`, libpnp_hip_dev.so: the product library reads no environment
+ * variable and records no stamps -- there this returns PNP_ERR_STATE).  A DEV build started with PNP_GEMM_STAMPS=1
+ * records, per workgroup of the wide-tile GEMM, the shader clock (slots 0-3) and the 100 MHz wall clock (slots 4-7) at
+ * kernel start, after the first slab landed, after the main loop and after the epilogue; this copies the last launch's
+ * stamps to the host. */
 int pnp_dbg_gemm_stamps(uint64_t* host_out, int32_t max_blocks);
 int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream);
 

@@ -343,13 +343,9 @@ template <typename T, int BM, int BN, int WTM, int WTN, int NS, bool PIPE = true
 static int launch_big(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const size_t smem = (size_t)NS * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return PNP_ERR_HIP;
-        attr_set = true;
-    }
+    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr != hipSuccess) return PNP_ERR_HIP;
     hipLaunchKernelGGL((gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>), dim3(nbm * nbn), dim3((BM / WTM) * (BN / WTN) * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
@@ -574,12 +570,33 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                 for (int j = 0; j < TM; j++) {
                     const bf16x8& fh = j < TM - 1 ? ah[j < TM - 1 ? j : 0] : xh;
                     const bf16x8& fl = j < TM - 1 ? al[j < TM - 1 ? j : 0] : xl;
+#ifdef PNP_X3_MFMA16_TIMING
+                    // TIMING-ONLY experiment (results are garbage): the same operands, registers and FLOPs per instruction
+                    // slot as two v_mfma_f32_16x16x32_bf16 on 4-register slices of the accumulator
+                    auto mm16 = [&](f32x16& c, const bf16x8& b, const bf16x8& a, int h) {
+                        f32x4 c0 = {c[8 * h + 0], c[8 * h + 1], c[8 * h + 2], c[8 * h + 3]}, c1 = {c[8 * h + 4], c[8 * h + 5], c[8 * h + 6], c[8 * h + 7]};
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            c[8 * h + e] = c0[e];
+                            c[8 * h + 4 + e] = c1[e];
+                        }
+                    };
+#pragma unroll
+                    for (int i = 0; i < TN; i++) mm16(acc[i][j], bl[i], fh, 0);
+#pragma unroll
+                    for (int i = 0; i < TN; i++) mm16(acc[i][j], bh[i], fl, 1);
+#pragma unroll
+                    for (int i = 0; i < TN; i++) mm16(acc[i][j], bh[i], fh, 0);
+#else
 #pragma unroll
                     for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[i], fh, acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], fl, acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], fh, acc[i][j], 0, 0, 0);
+#endif
                     if constexpr (decltype(dma)::value) {
                         issue_one(kt_d, 2 * j);
                         issue_one(kt_d, 2 * j + 1);
@@ -1010,20 +1027,16 @@ static int wide_epilogue_kind(const GemmArgs& g) {
 template <int EPI, bool X3>
 static int launch_wide(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
-    static int n_cu = 0;
-    if (!n_cu) {
+    static const int n_cu = [] {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return PNP_ERR_HIP;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI, X3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kWideSmem) != hipSuccess)
-            return PNP_ERR_HIP;
-        attr_set = true;
-    }
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    if (!n_cu) return PNP_ERR_HIP;
+    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideSmem);
+    if (attr != hipSuccess) return PNP_ERR_HIP;
     const int ntiles = nbm * nbn;
     int cap = n_cu;
 #ifdef PNP_DEV
@@ -1234,13 +1247,9 @@ template <int NW, int KS>
 static int launch_small_x3_t(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 63) / 64, nbn = g.N / 64;
     constexpr int smem = 4 * 4 * 64 * 64 * KS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small_x3_kernel<NW, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem) !=
-            hipSuccess)
-            return PNP_ERR_HIP;
-        attr_set = true;
-    }
+    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small_x3_kernel<NW, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (attr != hipSuccess) return PNP_ERR_HIP;
     hipLaunchKernelGGL((gemm_nt_small_x3_kernel<NW, KS>), dim3(nbm * nbn), dim3(NW * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
@@ -1374,13 +1383,9 @@ template <typename T, int BM, int BN>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const size_t smem = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return PNP_ERR_HIP;
-        attr_set = true;
-    }
+    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr != hipSuccess) return PNP_ERR_HIP;
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(nbm * nbn), dim3(256), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }

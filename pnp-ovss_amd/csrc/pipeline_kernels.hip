@@ -811,13 +811,9 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
     size_t d0, d1;
     lds_for(nt1, d0, d1);
     lds1 = d1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(blur_axis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return PNP_ERR_HIP;
-        attr_set = true;
-    }
+    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_axis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return PNP_ERR_HIP;
     const int tiles0 = ((maxW + 63) / 64) * ((maxH + 32 * nt0 - 1) / (32 * nt0));
     const int tiles1 = ((maxW + 64 * nt1 - 1) / (64 * nt1)) * ((maxH + 31) / 32);
     hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles0, Kmax, B), dim3(256 * nt0), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius, nt0);
@@ -828,13 +824,9 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
 int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, int group, hipStream_t s) {
     const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
     const size_t smem = (size_t)256 * (max_kp + 1) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set && smem > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(unary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-            hipSuccess)
-            return PNP_ERR_HIP;
-        attr_set = true;
-    }
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(unary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       160 * 1024);
+    if (attr != hipSuccess) return PNP_ERR_HIP;
     if (max_kp >= 32) {                                                    // wide rows: nothing parked in LDS
         const int nbw = (maxHW + 255) / 256 < 2048 ? (maxHW + 255) / 256 : 2048;
         hipLaunchKernelGGL(unary_wide_kernel, dim3(nbw, B), dim3(256), 0, s, maps, desc, unary, group);

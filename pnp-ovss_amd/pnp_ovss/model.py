@@ -53,6 +53,9 @@ class _Obj:
     pass
 
 
+MAX_TEXT_TOKENS = 192        # longest caption the text kernels take (csrc/text_kernels.hip TXT_MAX_L; pnp_create rejects more)
+
+
 class BlipITM(torch.nn.Module):
     """BLIP image-text matching model whose forward / GradCAM run in libpnp_hip.so.
 
@@ -113,6 +116,11 @@ class BlipITM(torch.nn.Module):
     def ensure_engine(self, img_size=None, batch=None, stash_layer=None, text_len=None):
         """Create (or, for a lazily built model, re-create) the engine so that it fits the call at hand.  Eager models
         only check and fail loudly, as before."""
+        if text_len is not None and text_len > MAX_TEXT_TOKENS:
+            # before anything is torn down: no engine can serve the call (the reference's tokenizer allows max_length = 500;
+            # the longest caption of the four datasets, ADE20K's 150 class names, is 155 tokens)
+            raise RuntimeError(f"caption of {text_len} tokens: the HIP text kernels take at most {MAX_TEXT_TOKENS} "
+                               f"(150-class prompts are 155); split the class list")
         eng = self._engine
         if eng is not None:
             fits = ((img_size is None or img_size == eng.cfg.img_size) and (batch is None or batch <= eng.max_batch) and
@@ -137,7 +145,7 @@ class BlipITM(torch.nn.Module):
         cfg = dataclasses.replace(self.cfg, img_size=int(img_size or self.cfg.img_size))
         if stash_layer is None:
             stash_layer = int(os.environ.get("PNP_OVSS_STASH_LAYER", 0))      # 0: all 12 x 12 maps, like the reference's return value
-        eng = Engine(cfg, max_batch=int(batch or lz["max_batch"]), max_text_len=min(192, max(64, int(text_len or 0))),
+        eng = Engine(cfg, max_batch=int(batch or lz["max_batch"]), max_text_len=min(MAX_TEXT_TOKENS, max(64, int(text_len or 0))),
                      stash_layer=int(stash_layer), mode=lz["mode"], device=self._device.index or 0)
         flat = self.weights_flat
         sd = {}
@@ -145,6 +153,15 @@ class BlipITM(torch.nn.Module):
             sd[n] = flat[o:o + int(np.prod(shp))].view(*shp)
         sd["visual_encoder.pos_embed"] = _resize_pos_embed(self.pos_embed_raw.cpu(), cfg.grid).to(flat.device)   # base_model.py:108-110
         eng.load_state_dict(sd)
+        if flat.is_cuda:
+            # the engine now holds its own (converted) copy: the 1.8 GB of fp32 leave the module's buffers -- a DDP wrapper
+            # would otherwise re-broadcast them on every DDP.forward under its default broadcast_buffers=True -- and stay
+            # on the host for the case that a later call needs a larger engine.  (A DDP wrapper built before the first
+            # call keeps its own reference to the device buffer: pass broadcast_buffers=False to release that one too.)
+            torch.cuda.synchronize()
+            host_copy = flat.cpu()
+            delattr(self, "weights_flat")                          # nn.Module.__delattr__: out of _buffers
+            self.weights_flat = host_copy                          # plain attribute now
         self.cfg, self._engine = cfg, eng
         self._last = self._grad_layer = None
         return eng
@@ -402,9 +419,20 @@ class Segmenter:
         if n_class > 256:
             raise ValueError("label maps are uint8: at most 256 classes")
         eng = self.m.engine
-        eng.post_reserve(eng.max_batch, eng.max_batch * max_pixels_per_image, max_pixels_per_image, max_channels, crf_chunk)
+        self._reserve = (max_pixels_per_image, max_channels, crf_chunk)
+        self._reserved_eng = None
+        self._reserve_on(eng)
         self.hist_1drop = torch.zeros(n_class * n_class, device=eng.device, dtype=torch.int64)
         self.hist_ndrop = torch.zeros(n_class * n_class, device=eng.device, dtype=torch.int64)
+
+    def _reserve_on(self, eng):
+        """Post-processing workspace of `eng` (a lazily built model may replace its engine between launches, e.g. a
+        (layer, head) sweep that reaches below the kept layers: the new engine needs its own reserve and prepare)."""
+        if self._reserved_eng is not eng:
+            px, ch, chunk = self._reserve
+            eng.post_reserve(eng.max_batch, eng.max_batch * px, px, ch, chunk)
+            self._reserved_eng = eng
+            self._prepared = None
 
     def prepare(self, captions, best_class_idx, org_images, label_trues, gt_dev=None):
         """Host-only half of a batch (no dependence on the model's results): tokenisation, word-piece merge plans, label
@@ -435,13 +463,15 @@ class Segmenter:
         """Device half: drop loop, merge, threshold / upsample, blur, CRF, argmax / remap, histogram into `hists`
         (default: self.hist_1drop / self.hist_ndrop).  Returns the two label-map lists (views of engine buffers: valid
         until the next launch); the tail of the work is still queued on the stream when this returns."""
-        m, eng = self.m, self.m.engine
+        m = self.m
         h1, hn = hists if hists is not None else (self.hist_1drop, self.hist_ndrop)
         g0, agg = drop_loop(args, m, prep["tok500"], imgs_in, prep["captions"])
+        eng = m.engine                                              # read AFTER the drop loop: it may have re-created the engine
+        self._reserve_on(eng)
         if self.coco and int(args.drop_iter) >= 3:
             run_1drop = False
         scale01 = (True, self.coco)                                 # Scale_0_1 on (1-drop, N-drop)
-        if getattr(self, "_prepared", None) is not prep:            # once per batch: a (layer, head) sweep re-launches the same prep
+        if getattr(self, "_prepared", None) is not prep:            # once per batch and engine: a (layer, head) sweep re-launches the same prep
             eng.post_prepare(prep["sizes"], prep["plans"], prep["luts"], prep["bgs"], rgb=prep["rgb"], gt=prep["gt"],
                              want_crf=bool(self.mode and "crf" in self.mode))
             self._prepared = prep

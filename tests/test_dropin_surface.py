@@ -372,3 +372,51 @@ def test_cli_layer_head_sweep_and_crf_only(tmp_path):
     for f in files:
         h = np.load(f)
         assert h.shape == (21, 21) and h.sum() == 2 * 336 * 336
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """The N > 1 path of bench.py under its real launcher with the real engines, on the one GPU a test box has: two rank
+    processes share cuda:0 over gloo (RCCL refuses two ranks on one device; the driver's scaling job is where RCCL itself
+    runs).  Mirrors PnP.py:1193-1225 (one process per rank, DDP-ctor weight broadcast) and :1439 (spawn): both ranks must
+    take part in the weight broadcast, the histogram all-reduce and the label gather -- the all-reduced confusion matrix
+    holds every pixel of both ranks' images, rank 0 ends up with two label-map buffers."""
+    steps, warm, B, S = 2, 1, 35, 336
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", str(steps),
+           "--warmup", str(warm), "--pipelines", "1", "--no-cpu-baseline", "--no-other-modes", "--no-other-configs", "--no-noise12"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["n_ranks"] == 2 and line["scaling"] == "weak"
+    assert line["images_per_rank"] == B * steps and line["gathered_label_maps"] == 2
+    col = line["collectives"]
+    assert col["gathered_label_bytes"] == [B * S * S] * 2                     # one uint8 label map set per rank
+    assert len(col["per_rank_images_per_sec"]) == 2 and min(col["per_rank_images_per_sec"]) > 0
+    # every step (warm-up included: the histogram state lives across them) counts each pixel once, on each rank
+    assert col["hist_ndrop_total"] == 2 * (steps + warm) * B * S * S
+    assert col["weight_bytes"] > 1.7e9 and line["value"] > 0
+
+
+def test_validate_real_kit_self_test(tmp_path):
+    """tools/validate_real.py (the one-command real-data check: CLI per parity mode -> Calculate_mIoU.py, per-image label
+    differences f32 vs bf16x3, dumped [7][9] maps) rehearsed end to end on a generated VOC-layout tree of JPEG files with a
+    BLIP-ITM-large-shaped .pth checkpoint and a word-piece vocabulary file -- the kit must run where the real files do not
+    exist, so that it works for whoever has them.  The split-bf16 mode must agree with the fp32 mode to north_star's 1e-4
+    on the dumped maps and on all but a fraction of a percent of the label pixels."""
+    out = tmp_path / "vr"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "validate_real.py"), "--self_test", "--max_batches", "2",
+                        "--out", str(out)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.load(open(out / "report.json"))
+    for mode in ("f32", "bf16x3"):
+        m = rep["miou"][mode]
+        assert m["cli_summary"]["images"] == 70 and 0 < m["n_drop"]["Mean IoU"] < 1 and "Mean IoU" in m["1_drop"]
+        assert abs(m["n_drop"]["Mean IoU"] - m["cli_summary"]["Mean IoU"]) < 1e-6       # files on disk == the run's own reduce
+    d = rep["f32_vs_bf16x3"]
+    assert d["images"] == 70 and d["map_7_9_max_abs_f32_vs_bf16x3"] < 1e-4
+    assert d["n_drop_label_pixels_differing"]["mean"] < 1e-3 and d["n_drop_label_pixels_differing"]["max"] < 2e-2
+    assert abs(rep["miou"]["f32"]["n_drop"]["Mean IoU"] - rep["miou"]["bf16x3"]["n_drop"]["Mean IoU"]) < 1e-3
+    z = np.load(out / "maps.npz")
+    assert z["map_7_9_f32"].shape == z["map_7_9_bf16x3"].shape and z["map_7_9_f32"].shape[0] == 3

@@ -56,6 +56,20 @@ def _norm01(m):
     return (m - lo) / np.maximum(hi - lo, 1e-30)
 
 
+def _nerr(tag, got, ref, reduce="max"):
+    """Error of the per-token min-max normalised maps (the pipeline's own normalisation, PnP.py:352-353) -- the bound that
+    means something with random weights, whose raw maps are ~1e-5 in size.  The measured value is printed (pytest -s) and,
+    with PNP_TEST_MEASURE_LOG set, appended to that file: the bounds in this file are ~2x what was measured on MI355X."""
+    d = np.abs(_norm01(got) - _norm01(ref))
+    v = float(d.max() if reduce == "max" else d.mean())
+    print(f"[normalised-map error] {tag}: {v:.3e}")
+    log = os.environ.get("PNP_TEST_MEASURE_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(json.dumps({"tag": tag, "value": v, "reduce": reduce}) + "\n")
+    return v
+
+
 # ------------------------------------------------------------------------------------------ operators
 
 @pytest.mark.parametrize("bf16", [False, True])
@@ -106,9 +120,14 @@ def test_gemm_split_bf16_x3(kind, shape):
     each fp32-facing epilogue, ragged M / N, one and several k-slabs, a problem smaller than one tile.  Against float64
     of the ORIGINAL fp32 operands: the error budget is the dropped lo.lo term and the 16-bit operand mantissas
     (2^-16 per product, random sign) plus fp32 accumulation -- about 1e-5 of |A|.|B| row norms, 300x below plain bf16."""
+    _x3_case(kind, *shape)
+
+
+def _x3_case(kind, M, N, K, tok=None):
+    """One pnp_op_gemm_x3 launch against float64 of the original fp32 operands, every output element compared.
+    tok = (col_div, col_pad) of the token-column epilogue (default: by K as the small cases always did)."""
     from pnp_ovss import hip
     lib = hip.load_library()
-    M, N, K = shape
     g = torch.Generator().manual_seed(M + K)
     A = torch.randn(M, K, generator=g).cuda()
     B = (torch.randn(N, K, generator=g) * 0.25).cuda()
@@ -124,6 +143,8 @@ def test_gemm_split_bf16_x3(kind, shape):
         div, pad = (442, 448) if K > 64 else (577, 640)       # even: token pairs per lane; odd: single tokens
         if M == 70:
             div, pad = 100, 128
+        if tok is not None:
+            div, pad = tok
         nimg = (N + div - 1) // div
         bias = torch.randn(M, generator=g).cuda()
         out = torch.zeros(M, nimg * pad, device="cuda")
@@ -238,9 +259,12 @@ def test_gemm_wide_tile_epilogues(kind, shape):
     """The 256 x 256 bf16 kernel (taken from 128 tiles up) with each of its compile-time epilogues; ragged M,
     N not a multiple of the tile, K = one slab and several.  Inputs are bf16-exact so only the fp32
     accumulation order (and, for bf16 outputs, the final rounding: 2^-8 relative) differs from fp64."""
+    _wide_bf16_case(kind, *shape)
+
+
+def _wide_bf16_case(kind, M, N, K, tok=None):
     from pnp_ovss import hip
     lib = hip.load_library()
-    M, N, K = shape
     g = torch.Generator().manual_seed(M + K)
     A = (torch.randn(M, K, generator=g)).to(torch.bfloat16).cuda()
     B = (torch.randn(N, K, generator=g) * 0.25).to(torch.bfloat16).cuda()
@@ -248,6 +272,8 @@ def test_gemm_wide_tile_epilogues(kind, shape):
     p = lambda t: t.data_ptr() if t is not None else None
     if kind == "tokcols":
         div, pad = (442, 448) if K > 64 else (577, 640)      # even: token pairs per lane; odd: single tokens
+        if tok is not None:
+            div, pad = tok
         nimg = (N + div - 1) // div
         bias = torch.randn(M, generator=g).cuda()
         out = torch.zeros(M, nimg * pad, device="cuda", dtype=torch.bfloat16)
@@ -285,6 +311,40 @@ def test_gemm_wide_tile_epilogues(kind, shape):
         ref = torch.nn.functional.gelu(ref)
     err = float((out.double() - ref).abs().max())
     assert err <= 2 ** -8 * float(ref.abs().max()) + 1e-3, err
+
+
+# The launches bench.py times (BASELINE config 2: B = 35 images x 442 tokens = 15 470 rows through BLIP's ViT-L block and the
+# cross K / V projections of all 12 text layers).  The wide kernel is PERSISTENT: grid = min(tiles, CUs), so a workgroup walks
+# several 256 x 256 tiles only when a launch has more than 256 of them, prefetching the next tile's first slab during its
+# epilogue (csrc/gemm.hip, "Tile hand-over").  These shapes have 244 / 732 / 976 / 2196 tiles: the multi-round path, the
+# ragged last row tile (15 470 = 60 x 256 + 110) and K = 1024 / 4096 with the epilogue each launch uses in the engine.
+BENCH_M = 35 * 442
+BENCH_LAUNCHES = [
+    # (form, epilogue, M, N, K, token-column geometry)          engine.hip launch it mirrors
+    ("x3", "plain_split", BENCH_M, 3072, 1024, None),          # qkv            -> (hi, lo) pair          EPI 7
+    ("x3", "gelu_split", BENCH_M, 4096, 1024, None),           # fc1 + GELU     -> (hi, lo) pair          EPI 6
+    ("x3", "resid_f32", BENCH_M, 1024, 4096, None),            # fc2 + residual -> fp32 in place          EPI 2
+    ("x3", "resid_f32", BENCH_M, 1024, 1024, None),            # proj + residual                          EPI 2
+    ("x3", "bias_f32", BENCH_M, 9216, 1024, None),             # cross K, all 12 text layers -> fp32      EPI 4
+    ("x3", "tokcols_f32", 9216, BENCH_M, 1024, (442, 448)),    # cross V^T, per-image padded token columns EPI 5
+    ("bf16", "bias_bf16", BENCH_M, 3072, 1024, None),          # qkv                                      EPI 0
+    ("bf16", "gelu_bf16", BENCH_M, 4096, 1024, None),          # fc1 + GELU                               EPI 1
+    ("bf16", "resid_f32", BENCH_M, 1024, 4096, None),          # fc2 + residual                           EPI 2
+    ("bf16", "resid_f32", BENCH_M, 1024, 1024, None),          # proj + residual
+    ("bf16", "bias_bf16", BENCH_M, 9216, 1024, None),          # cross K
+    ("bf16", "tokcols", 9216, BENCH_M, 1024, (442, 448)),      # cross V^T                                EPI 3
+]
+
+
+@pytest.mark.parametrize("form,kind,M,N,K,tok", BENCH_LAUNCHES, ids=[f"{c[0]}-{c[1]}-{c[2]}x{c[3]}x{c[4]}" for c in BENCH_LAUNCHES])
+def test_gemm_wide_at_bench_launch_shapes(form, kind, M, N, K, tok):
+    """gemm_nt_wide_kernel<EPI, X3> at exactly the launches the bench times, every output element against float64."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    assert tiles > 256 or tiles == 244            # several tiles per workgroup, or (N = 1024) one round that leaves 12 CUs idle
+    if form == "x3":
+        _x3_case(kind, M, N, K, tok)
+    else:
+        _wide_bf16_case(kind, M, N, K, tok)
 
 
 def test_layernorm():
@@ -429,14 +489,14 @@ def test_gradcam_small_vs_reference_golden(bf16):
         if bf16 == "bf16x3":                              # parity bounds of the fp32 mode, maps slightly looser in relative terms
             np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-3)
             assert np.abs(got - ref).max() < 1e-4
-            assert np.abs(_norm01(got) - _norm01(ref)).max() < 5e-3
+            assert _nerr(f"test_gradcam_small_vs_reference_golden[{bf16}] #1", got, ref) < 3e-4          # measured 1.2e-4
         elif not bf16:
             np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-3)
             assert np.abs(got - ref).max() < 1e-4          # north_star: float saliency maps within 1e-4 max-abs
-            assert np.abs(_norm01(got) - _norm01(ref)).max() < 2e-3
+            assert _nerr(f"test_gradcam_small_vs_reference_golden[{bf16}] #2", got, ref) < 2e-4          # measured 8.7e-5
         else:
             assert np.abs(got - ref).max() < 0.05 * ref.max() + 1e-4
-            assert np.abs(_norm01(got) - _norm01(ref)).mean() < 0.02
+            assert _nerr(f"test_gradcam_small_vs_reference_golden[{bf16}] #3", got, ref, "mean") < 0.02
     if bf16 is False:
         # stash layout: (B, heads, L, Nst) with the call's B and L, Nst = 64-padded image tokens
         P = e.buffer("P")[: 2 * 12 * L * 64].view(2, 12, L, 64)[..., : cfg.n_img_tokens].cpu().numpy()
@@ -490,11 +550,11 @@ def test_gradcam_large_336_vs_reference_golden(bf16):
     got, ref = out.cpu().numpy(), g["map_7_9"]
     if bf16 is not True:                     # fp32 and split-bf16: north_star's tolerance against the reference's own run
         assert np.abs(got - ref).max() < 1e-4
-        assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < (5e-3 if bf16 is False else 1e-2)
+        assert _nerr(f"test_gradcam_large_336_vs_reference_golden[{bf16}] #4", got[:, 3:-1], ref[:, 3:-1]) < (5e-4 if bf16 is False else 1e-3)   # measured 2.1e-4 / 4.5e-4
         np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=2e-2)
     else:
         assert np.abs(got - ref).max() < 0.1 * ref.max()
-        assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).mean() < 0.03
+        assert _nerr(f"test_gradcam_large_336_vs_reference_golden[{bf16}] #5", got[:, 3:-1], ref[:, 3:-1], "mean") < 0.03
     if bf16 is not True:
         # two more (layer, head) pairs from the same forward: layers 9 and 10 (the last layer's map [11][3] is identically
         # zero -- only the dropped [ENC] row has a gradient there -- and would say nothing)
@@ -503,7 +563,7 @@ def test_gradcam_large_336_vs_reference_golden(bf16):
             torch.cuda.synchronize()
             assert g[key].max() > 0
             assert np.abs(out2.cpu().numpy() - g[key]).max() < 1e-4
-            assert np.abs(_norm01(out2.cpu().numpy()[:, 3:-1]) - _norm01(g[key][:, 3:-1])).max() < (5e-3 if bf16 is False else 2e-2)
+            assert _nerr(f"test_gradcam_large_336_vs_reference_golden[{bf16}] #6", out2.cpu().numpy()[:, 3:-1], g[key][:, 3:-1]) < (5e-4 if bf16 is False else 5e-4)   # measured 2.3e-4 / 1.9e-4
 
 
 # ------------------------------------------------------------------------------------------ post-process
@@ -722,7 +782,7 @@ def test_full_size_properties_336():
     cfg = C.blip_itm_large(336)
     from pnp_ovss.hip import Engine
     _ENG.clear()
-    e = Engine(cfg, max_batch=2, max_text_len=32, stash_layer=7, bf16=True)
+    e = Engine(cfg, max_batch=2, max_text_len=32, stash_layer=7, mode="bf16x3")     # the benchmarked mode
     e.load_state_dict(synth.synth_state_dict(cfg, 0))
     B = 2
     rgb, imgs = synth.synth_images(B, 336, seed=1234)
@@ -832,11 +892,22 @@ def test_whole_path_full_size_properties_per_config(name, img, n_cls, data_type,
 
 # ------------------------------------------------------------------------------------------ end to end
 
+# "argmax label maps bit-exact" (north_star) holds stage by stage on identical inputs (tests above); END TO END the model's
+# floating-point maps differ from the reference's in the last bits (fp32 summation order; for bf16x3 the 2^-16 per-product
+# error of the split operands), so a label can differ exactly where the two best channels of a pixel are closer than that
+# error: a flip is accepted only where their relative gap is below ~2x the largest gap measured at a flipped pixel of the
+# four fixtures on MI355X (f32: 1.3e-5, bf16x3: 1.9e-4 -- the size of each mode's normalised-map error), and the number of
+# flipped pixels is bounded as well (measured: at most 148 of 34 684, all in one no-post-process output of pipeline_psc).
+E2E_TIE = {"f32": 3e-5, "bf16x3": 4e-4}
+
+@pytest.mark.parametrize("mode_", ["f32", "bf16x3"])
 @pytest.mark.parametrize("fname", ["pipeline_voc.npz", "pipeline_psc.npz"])
-def test_end_to_end_f32_labels_vs_reference_run(fname):
-    """Whole path in fp32 mode (model -> drop loop -> merge -> threshold/upsample -> blur -> argmax ->
-    remap) against the label maps the REFERENCE ITSELF produced (save_img_union_attention, golden),
-    and with CRF against the oracle.  Only float near-ties may differ."""
+def test_end_to_end_labels_vs_reference_run(fname, mode_):
+    """Whole path (model -> drop loop -> merge -> threshold/upsample -> blur -> argmax -> remap) in BOTH parity modes --
+    the exact-fp32 one and the benchmarked split-bf16 one -- against the label maps the REFERENCE ITSELF produced
+    (save_img_union_attention, golden), and with CRF against the oracle.  Only float near-ties may differ: a flip is
+    accepted only where the two best channels of the device's own blurred maps agree to 1e-4 relative (the same rule for
+    both modes); the count of flipped pixels is bounded as well."""
     g = _golden(fname)
     cfg = _cfg(g)
     data_type = str(g["data_type"])
@@ -858,7 +929,7 @@ def test_end_to_end_f32_labels_vs_reference_run(fname):
     enc = tok(caps, padding="max_length", max_length=500)
     ids, mask = enc.input_ids.numpy(), enc.attention_mask.numpy()
     L = int(mask.sum(1).max())
-    e = _engine(cfg, int(g["weight_seed"]), False)
+    e = _engine(cfg, int(g["weight_seed"]), mode_)
     if not getattr(e, "_reserved", False):
         e.post_reserve(4, 4 * 128 * 128, 128 * 128, 8, 0)
         e._reserved = True
@@ -878,15 +949,23 @@ def test_end_to_end_f32_labels_vs_reference_run(fname):
             labels = e.split_labels(e.postprocess(src, 0.15, scale01, mode))
             torch.cuda.synchronize()
             maps = [m.cpu().numpy() for m in e.post_maps("maps")]
-            bad = 0
+            bad = flips = 0
+            gap = 0.0
             for i in range(B):
                 ref = g[f"labels_{name}_{mode or 'none'}_{i}"]
                 diff = labels[i].cpu().numpy() != ref
+                flips += int(diff.sum())
                 if maps[i].shape[0] > 1:                           # a flip is legitimate only where the two best
-                    srt = np.sort(maps[i], axis=0)                 # channels agree to float rounding (proportional maps)
-                    diff &= ~((srt[-1] - srt[-2]) <= 1e-4 * np.abs(srt[-1]))
+                    srt = np.sort(maps[i], axis=0)                 # channels agree to the mode's map error (proportional maps)
+                    rel = (srt[-1] - srt[-2]) / np.maximum(np.abs(srt[-1]), 1e-30)
+                    if diff.any():
+                        gap = max(gap, float(rel[diff].max()))
+                    diff &= ~(rel <= E2E_TIE[mode_])
                 bad += int(diff.sum())
-            assert bad == 0, (name, mode, bad)
+            print(f"[e2e {fname} {mode_} {name} {mode}] label pixels differing from the reference's: {flips} of {total}, "
+                  f"largest relative gap between the two best channels at such a pixel {gap:.2e}")
+            assert bad == 0, (name, mode, bad, gap)
+            assert flips <= 0.005 * total, (name, mode, flips)
     # blur + CRF: device path vs the oracle run on the same inputs end to end
     W = synth.synth_state_dict(cfg, int(g["weight_seed"]))
     pieces_o = [host.caption_pieces(tok, ids[i]) for i in range(B)]
@@ -897,9 +976,11 @@ def test_end_to_end_f32_labels_vs_reference_run(fname):
     assert bad <= 0.003 * total, bad
 
 
+@pytest.mark.parametrize("mode_", ["f32", "bf16x3"])
 @pytest.mark.parametrize("fname", ["pipeline_coco_object.npz", "pipeline_coco_stuff.npz"])
-def test_end_to_end_coco_driver_vs_reference_run(fname):
-    """BASELINE config 4 semantics: the product's Segmenter (as the COCO command line drives it) in fp32 mode against
+def test_end_to_end_coco_driver_vs_reference_run(fname, mode_):
+    """BASELINE config 4 semantics: the product's Segmenter (as the COCO command line drives it) in both parity modes (the
+    exact-fp32 one and the benchmarked split-bf16 one) against
     the label maps and .npy confusion matrices the reference's COCO driver itself produced
     (PnP_OVSS_0514_updated_segmentation_coco.py save_img_union_attention; tests/golden/make_golden.py): drop_iter 4 ->
     N-drop branch only, drop_iter 2 -> both branches, Scale_0_1 on both, background rule, category-id remap, 91 / 183
@@ -913,7 +994,7 @@ def test_end_to_end_coco_driver_vs_reference_run(fname):
     n_class = int(g["n_class"])
     from pnp_ovss.hip import Engine
     _ENG.clear()
-    e = Engine(cfg, max_batch=4, max_text_len=40, stash_layer=7, bf16=False)     # own engine: the Segmenter reserves its workspace
+    e = Engine(cfg, max_batch=4, max_text_len=40, stash_layer=7, mode=mode_)     # own engine: the Segmenter reserves its workspace
     e.load_state_dict(synth.synth_state_dict(cfg, int(g["weight_seed"])))
     model = BlipITM(cfg, e, c["tok"])
     segs = {}
@@ -941,9 +1022,10 @@ def test_end_to_end_coco_driver_vs_reference_run(fname):
                 n += int(diff.sum())
                 if name == "ndrop" and maps[i].shape[0] > 1:
                     srt = np.sort(maps[i], axis=0)
-                    diff &= ~((srt[-1] - srt[-2]) <= 1e-4 * np.abs(srt[-1]))
+                    diff &= ~((srt[-1] - srt[-2]) <= E2E_TIE[mode_] * np.abs(srt[-1]))
                     bad += int(diff.sum())
             total = sum(h * w for h, w in c["sizes"])
+            print(f"[e2e {fname} {mode_} {tag} {name}] label pixels differing from the reference's: {n} of {total}")
             assert bad == 0 and n <= 0.002 * total, (tag, name, bad, n)
             if n == 0:                                            # same labels -> the saved .npy must be identical
                 np.testing.assert_array_equal(hist.cpu().numpy().reshape(n_class, n_class), g[f"hist_{name}_{tag}"].astype(np.int64))
@@ -1006,20 +1088,21 @@ def test_drop_loop_large_vs_reference_golden(mode):
             assert ref_set == set(picks[b, : it * 10].tolist()), (mode, it, b, sorted(ref_set ^ set(picks[b, : it * 10].tolist())))
     got0, gota = g0.cpu().numpy(), agg.cpu().numpy()
     assert np.abs(got0 - g["g0"]).max() < 1e-4 and np.abs(gota - g["agg"]).max() < 1e-4
-    tol = 5e-3 if mode == "f32" else 2e-2
+    tol = 5e-4 if mode == "f32" else 7e-4          # ~2x the measured 2.2e-4 / 3.0e-4
     for b, n in enumerate(ncls):               # class rows only: rows past the caption are zero in both
         sl = slice(3, 3 + n)
-        assert np.abs(_norm01(got0[b, sl]) - _norm01(g["g0"][b, sl])).max() < tol
-        assert np.abs(_norm01(gota[b, sl]) - _norm01(g["agg"][b, sl])).max() < tol
+        assert _nerr(f"test_drop_loop_large_vs_reference_golden[{mode}] #7", got0[b, sl], g["g0"][b, sl]) < tol
+        assert _nerr(f"test_drop_loop_large_vs_reference_golden[{mode}] #8", gota[b, sl], g["agg"][b, sl]) < tol
 
 
-def test_bf16x3_picks_equal_f32_at_blip_large_batch8():
-    """Pick parity of the benchmarked mode at full model size (what tools/precision_probe.py measured, as a test): eight
-    images through BLIP-ITM-large 336^2, drop_iter 4, 20-class prompt -- the split-bf16 mode must choose exactly the
-    patches the exact-fp32 mode chooses in all 8 x 4 (image, iteration) pairs, and its aggregated map must agree to 1e-4
-    absolute / 2 % of the per-token range."""
+def test_bf16x3_picks_equal_f32_at_blip_large_batch35():
+    """Pick parity of the benchmarked mode at full model size AND at the bench's batch (B = 35: the wide GEMM's multi-tile
+    launches, 732 / 976 tiles on 256 CUs, are part of what is compared): 35 images through BLIP-ITM-large 336^2, drop_iter 4,
+    20-class prompt -- the split-bf16 mode must choose exactly the patches the exact-fp32 mode chooses in all 35 x 4
+    (image, iteration) pairs, and its aggregated map must agree to 1e-4 absolute and, normalised per token, to ~2x the
+    measured error."""
     cfg = C.blip_itm_large(336)
-    B = 8
+    B = 35
     _, imgs = synth.synth_images(B, 336, seed=515)
     ids, mask = synth.synth_tokens(cfg, [20] * B, seed=515)
     L = int(mask.sum(1).max())
@@ -1033,7 +1116,7 @@ def test_bf16x3_picks_equal_f32_at_blip_large_batch8():
     bad = [(b, it) for b in range(B) for it in range(1, 5) if set(pf[b, : 10 * it].tolist()) != set(px[b, : 10 * it].tolist())]
     assert not bad, f"pick sets differ in (image, iteration) pairs {bad}"
     assert np.abs(ax - af).max() < 1e-4
-    assert np.abs(_norm01(ax[:, 3:-1]) - _norm01(af[:, 3:-1])).max() < 2e-2
+    assert _nerr("test_bf16x3_picks_equal_f32_at_blip_large_batch35 agg #9", ax[:, 3:-1], af[:, 3:-1]) < 1.2e-3      # measured 5.9e-4 over 35 images
     # ... and all the way to the label maps: the same post-processing (threshold / upsample / blur / DenseCRF / remap) of the two
     # aggregated maps may differ only where two channels are a near-tie (measured 0.03-0.15 % of the pixels; bound 0.5 %)
     e = _engine(cfg, 0, "f32", max_batch=B, max_text_len=32)
@@ -1067,7 +1150,7 @@ def test_gradcam_long_caption_vs_oracle(n_classes):
         got = out.cpu().numpy()
         assert got.shape == ref.shape == (2, L - 1, 8, 8)
         assert np.abs(got - ref).max() < 1e-4
-        assert np.abs(_norm01(got[0, 3:-1]) - _norm01(ref[0, 3:-1])).max() < 2e-2
+        assert _nerr(f"test_gradcam_long_caption_vs_oracle[{mode}] #10", got[0, 3:-1], ref[0, 3:-1]) < (4e-4 if mode == "f32" else 8e-4)   # measured 1.7e-4 / 3.8e-4
         np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, rtol=0, atol=2e-2)
 
 
@@ -1088,7 +1171,7 @@ def test_gradcam_large_768_vs_reference_golden(mode):
     got, ref = out.cpu().numpy(), g["map_7_9"]
     assert got.shape == ref.shape == (1, L - 1, 48, 48)
     assert np.abs(got - ref).max() < 1e-4
-    assert np.abs(_norm01(got[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < (1e-2 if mode == "f32" else 3e-2)
+    assert _nerr(f"test_gradcam_large_768_vs_reference_golden[{mode}] #11", got[:, 3:-1], ref[:, 3:-1]) < (1e-3 if mode == "f32" else 1.3e-3)   # measured 5.0e-4 / 6.5e-4
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=5e-2)
     # a second (layer, head): layer 9 -- the last text layer's map is identically zero (only the dropped [ENC] row has a
     # gradient there), so [11][3] says nothing
@@ -1096,7 +1179,7 @@ def test_gradcam_large_768_vs_reference_golden(mode):
     torch.cuda.synchronize()
     assert g["map_9_3"].max() > 0 and np.abs(g["map_11_3"]).max() == 0
     assert np.abs(out2.cpu().numpy() - g["map_9_3"]).max() < 1e-4
-    assert np.abs(_norm01(out2.cpu().numpy()[:, 3:-1]) - _norm01(g["map_9_3"][:, 3:-1])).max() < (1e-2 if mode == "f32" else 3e-2)
+    assert _nerr(f"test_gradcam_large_768_vs_reference_golden[{mode}] #12", out2.cpu().numpy()[:, 3:-1], g["map_9_3"][:, 3:-1]) < (4e-4 if mode == "f32" else 9e-4)   # measured 1.5e-4 / 4.4e-4
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
@@ -1116,7 +1199,7 @@ def test_gradcam_large_59_class_caption_vs_oracle(mode):
     maps, ref_logits, _ = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7])
     ref = maps[7][:, 9]
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
-    assert np.abs(_norm01(out.cpu().numpy()[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < (5e-3 if mode == "f32" else 2e-2)
+    assert _nerr(f"test_gradcam_large_59_class_caption_vs_oracle[{mode}] #13", out.cpu().numpy()[:, 3:-1], ref[:, 3:-1]) < (1e-3 if mode == "f32" else 2.7e-3)   # measured 4.8e-4 / 1.33e-3
     np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, rtol=0, atol=2e-2)
 
 
@@ -1178,7 +1261,7 @@ def test_gradcam_768_geometry_vs_oracle():
     maps, ref_logits, _ = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7])
     ref = maps[7][:, 9]
     assert np.abs(out.cpu().numpy() - ref).max() < 1e-4
-    assert np.abs(_norm01(out.cpu().numpy()[:, 3:-1]) - _norm01(ref[:, 3:-1])).max() < 5e-3
+    assert _nerr("test_gradcam_768_geometry_vs_oracle[f32] #14", out.cpu().numpy()[:, 3:-1], ref[:, 3:-1]) < 1e-4   # measured 3.1e-5
     np.testing.assert_allclose(logits.cpu().numpy(), ref_logits, atol=2e-2)
     # 768-sized post-process (blur radius 154) vs the oracle, bit-exact
     e.post_reserve(1, 768 * 768, 768 * 768, 8, 0)
@@ -1351,3 +1434,143 @@ def test_jpeg_decode_on_device_matches_pillow():
         img = Image.open(io.BytesIO(files[k])).convert("RGB")
         x = np.asarray(img.resize((32, 32), Image.BICUBIC), dtype=np.float32).transpose(2, 0, 1) / np.float32(255.0)
         assert np.array_equal(got[k], (x - mean) / std)
+
+
+# ------------------------------------------------------------------------------------------ DenseCRF at the benchmark geometry
+
+def _photo_like(h, w, seed):
+    """Smooth gradients + texture + per-pixel noise: many more bilateral lattice points per pixel than the 8 x 8 block images."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 90 * np.sin(xx / 37.0 + yy / 91.0), 128 + 80 * np.cos(xx / 53.0 - yy / 29.0), (xx + 2 * yy) % 256], -1)
+    return np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+
+
+def test_densecrf_full_size_bit_exact_vs_oracle():
+    """Blur + DenseCRF at the benchmark geometry against the oracle (PnP.py:1030-1074): one 336 x 336 image of the bench's
+    own generator and one 375 x 500 (VOC-sized, non-square) photo-like image, K = 21 channels (20 classes + background).
+    Every stage bit-exact (threshold / upsample, blur), CRF labels bit-exact, marginals <= 1e-6, the number of bilateral
+    lattice points equal.  Sizes at which the 32-bit row offsets, the image-id bits of the sort keys and the splat's
+    multi-pass forms are the ones the bench runs (the small-geometry tests stop at 128 x 128)."""
+    cfg = C.blip_itm_small(336)                                  # post-processing only sees the 21 x 21 patch grid
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    rng = np.random.default_rng(21)
+    sizes = [(336, 336), (375, 500)]
+    n_cls, K = 20, 21
+    T = 3 + n_cls + 1
+    maps = rng.random((2, T, cfg.grid, cfg.grid), dtype=np.float32) ** 3
+    maps[:, 3 + n_cls:] = 0
+    rgb0, _ = synth.synth_images(1, 336, seed=1234, noise=4)
+    rgb = [rgb0[0], _photo_like(375, 500, 7)]
+    gts = [rng.integers(0, 21, size=s).astype(np.float32) for s in sizes]
+    e = Engine(cfg, max_batch=2, max_text_len=32, stash_layer=7, mode="f32")
+    e.post_reserve(2, sum(h * w for h, w in sizes), 375 * 500, K, 0)
+    plans = [[([i], 1) for i in range(n_cls)]] * 2
+    e.post_prepare(sizes, plans, [list(range(K))] * 2, [True, True], rgb=_dev(np.concatenate([r.reshape(-1) for r in rgb])),
+                   gt=_dev(np.concatenate([x.reshape(-1) for x in gts])), want_crf=True)
+    e.merge_tokens(_dev(maps))
+    e.threshold_upsample(0.15, False)
+    e.blur_minmax()
+    torch.cuda.synchronize()
+    blurred = [m.cpu().numpy() for m in e.post_maps("maps")]
+    e.densecrf()
+    hist = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    labels = e.split_labels(e.remap_hist(True, 21, hist))
+    torch.cuda.synchronize()
+    qs = e.post_q()
+    idb = e.buffer("crf_idbase_bilateral", torch.int32)[:3].cpu().numpy()
+    ref_labels = []
+    for b, (h, w) in enumerate(sizes):
+        pre = OP.threshold_upsample(maps[b][3:3 + n_cls], h, w, 0.15, False, True)
+        rb = np.stack([OP.blurring(pre[k], (h, w)) for k in range(K)])
+        np.testing.assert_array_equal(blurred[b], rb)
+        lab, q, stats = OP.densecrf(rgb[b], rb, want_q=True)
+        assert idb[b + 1] - idb[b] == stats[1], (b, idb, stats)                    # same bilateral lattice
+        np.testing.assert_array_equal(labels[b].cpu().numpy().astype(np.float32), lab)
+        np.testing.assert_allclose(qs[b].cpu().numpy().T.reshape(K, h, w), q, rtol=0, atol=1e-6)
+        ref_labels.append(lab)
+        print(f"[crf full size] image {b}: {stats[1]} bilateral lattice points = {stats[1] / (h * w):.2f} per pixel, "
+              f"{float((lab != np.argmax(rb, 0)).mean()):.3f} of the labels moved by the CRF")
+    _, ref_hist = OP.scores(gts, ref_labels, 21)
+    np.testing.assert_array_equal(hist.cpu().numpy().reshape(21, 21), ref_hist.astype(np.int64))
+    e.close()
+
+
+def test_densecrf_bench_batch_paired_equals_single_image_runs_and_oracle():
+    """The bench's post-processing launch -- B = 35 images of 336 x 336, K = 21, the 1-drop and N-drop branches paired as two
+    channel groups of one DenseCRF run (rows of 44 floats) -- must equal, bit for bit, 35 x 2 single-image single-branch
+    runs (nothing of an image's result may depend on what else is in the batch), and the oracle on the first images."""
+    cfg = C.blip_itm_small(336)
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    B, n_cls, K, S = 35, 20, 21, 336
+    rng = np.random.default_rng(35)
+    T = 3 + n_cls + 1
+    m1 = rng.random((B, T, cfg.grid, cfg.grid), dtype=np.float32) ** 3
+    m1[:, 3 + n_cls:] = 0
+    mn = m1 * 2 + (rng.random(m1.shape, dtype=np.float32) ** 3) * (m1 > 0)       # "agg": larger, different maps, same zero rows
+    rgb, _ = synth.synth_images(B, S, seed=1234, noise=4)
+    gt = rng.integers(0, 21, size=(B, S, S)).astype(np.float32)
+    e = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, mode="f32")
+    e.post_reserve(B, B * S * S, S * S, K, 0)
+    plan, lut = [([i], 1) for i in range(n_cls)], list(range(K))
+    d_rgb, d_gt = _dev(rgb.reshape(-1)), _dev(gt.reshape(-1))
+    e.post_prepare([(S, S)] * B, [plan] * B, [lut] * B, [True] * B, rgb=d_rgb, gt=d_gt, want_crf=True)
+    d1, dn = _dev(m1), _dev(mn)
+    h1 = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    hn = torch.zeros(21 * 21, device="cuda", dtype=torch.int64)
+    l1, ln = e.postprocess_pair(d1, dn, 0.15, 21, h1, hn)
+    torch.cuda.synchronize()
+    l1, ln = l1.view(B, S * S).clone(), ln.view(B, S * S).clone()
+    s1 = torch.zeros_like(h1)
+    sn = torch.zeros_like(hn)
+    for b in range(B):
+        e.post_prepare([(S, S)], [plan], [lut], [True], rgb=d_rgb[b * S * S * 3:(b + 1) * S * S * 3].clone(),
+                       gt=d_gt[b * S * S:(b + 1) * S * S].clone(), want_crf=True)
+        a = e.postprocess(d1[b:b + 1].contiguous(), 0.15, True, "blur+crf", 21, s1)
+        assert torch.equal(a, l1[b]), f"1-drop labels of image {b} differ between the paired batch and a single-image run"
+        a = e.postprocess(dn[b:b + 1].contiguous(), 0.15, False, "blur+crf", 21, sn)
+        assert torch.equal(a, ln[b]), f"N-drop labels of image {b} differ between the paired batch and a single-image run"
+    torch.cuda.synchronize()
+    assert torch.equal(s1, h1) and torch.equal(sn, hn)
+    assert int(h1.sum()) == B * S * S
+    for b in range(4):                                                           # and the oracle, both branches' scaling rules
+        for maps, scale01, got in ((m1, True, l1), (mn, False, ln)):
+            pre = OP.threshold_upsample(maps[b][3:3 + n_cls], S, S, 0.15, scale01, True)
+            lab = OP.postprocess("blur+crf", pre, rgb[b], (S, S))
+            np.testing.assert_array_equal(got[b].cpu().numpy().reshape(S, S).astype(np.float32), lab)
+    e.close()
+
+
+def test_merge_tokens_kernel_on_real_tokenizer_splits():
+    """merge_tokens_kernel fed with the plans of real BertTokenizer splits of the datasets' class names (up to 245 word
+    pieces for 50 words: tokenizer_cases.json) -- bit-exact against the word-level statement of the reference's merge
+    (tests/test_host_logic.py:expected_word_merge, PnP.py:810-853)."""
+    from test_host_logic import wordpiece_merge_cases, expected_word_merge
+    from pnp_ovss import host
+    from pnp_ovss.hip import Engine
+    cfg = C.blip_itm_small(128)
+    _ENG.clear()
+    cases = [c for c in wordpiece_merge_cases() if len(c[1]) + 5 <= 192]       # captions the text kernels take (L <= 192)
+    assert len(cases) >= 7
+    e = Engine(cfg, max_batch=len(cases), max_text_len=192, stash_layer=7, mode="f32")
+    Cmax = max(len(c[2]) for c in cases)
+    S = 32
+    e.post_reserve(len(cases), len(cases) * S * S, S * S, Cmax + 1, 0)
+    T = max(len(c[1]) for c in cases) + 4
+    rng = np.random.default_rng(3)
+    maps = rng.random((len(cases), T, cfg.grid, cfg.grid), dtype=np.float32)
+    plans = [host.merge_plan(c[1], len(c[2])) for c in cases]
+    bgs = [host.has_background("psc", len(c[2])) for c in cases]
+    luts = [list(range(len(c[2]) + int(b))) for c, b in zip(cases, bgs)]
+    e.post_prepare([(S, S)] * len(cases), plans, luts, bgs, rgb=None, gt=None, want_crf=False)
+    e.merge_tokens(_dev(maps))
+    torch.cuda.synchronize()
+    PP = cfg.grid * cfg.grid
+    merged = e.buffer("merged")[: len(cases) * Cmax * PP].view(len(cases), Cmax, cfg.grid, cfg.grid)     # [b][c] rows, c < Cmax of the batch
+    for b, (i, pieces, words, spans) in enumerate(cases):
+        got = merged[b, : len(words)].cpu().numpy()
+        m = maps[b][: 3 + len(pieces) + 1]                      # rows past this caption's [SEP] belong to longer captions
+        np.testing.assert_array_equal(got, expected_word_merge(m, spans), err_msg=f"caption {i}")
+    e.close()

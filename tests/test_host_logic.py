@@ -250,3 +250,72 @@ def test_host_tables_equal_sequential_reference_semantics_randomised():
             assert ours == [([i], 1) for i in range(len(names))]
         else:
             assert ours == ref, (names, pieces)
+
+
+def wordpiece_merge_cases():
+    """(caption index, pieces, class words, per-word piece spans) for the class-name captions of tokenizer_cases.json:
+    every VOC / Pascal-Context / ADE20K / COCO class word as HF's BertTokenizer splits it on the committed vocabulary
+    (ids pinned by the fixture).  Shared with the GPU twin in test_hip_parity.py."""
+    from pnp_ovss.tokenizer import WordPieceTokenizer
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "tokenizer_cases.json")))
+    tok = WordPieceTokenizer(os.path.join(ROOT, "tests", "golden", "tiny_vocab.txt"))
+    cases = []
+    for i, cap in enumerate(g["captions"][:9]):
+        ids = g["max_length_500"]["input_ids"][i]                 # HF's own ids, not re-tokenised
+        pieces = host.caption_pieces(tok, ids)
+        words = cap.split()[3:]
+        spans, p = [], 0
+        for w in words:                                           # a word = one plain piece + its ## continuations
+            q = p + 1
+            while q < len(pieces) and pieces[q].startswith("##"):
+                q += 1
+            assert "".join(x[2:] if x.startswith("##") else x for x in pieces[p:q]) == w, (w, pieces[p:q])
+            spans.append((p, q))
+            p = q
+        assert p == len(pieces)
+        cases.append((i, pieces, words, spans))
+    return cases
+
+
+def expected_word_merge(maps, spans):
+    """What Mean_over_filtered_label_tokens (PnP.py:810-853) computes, stated per class WORD instead of as a token walk:
+    a word's map is the in-order sum of its pieces' rows of map[3:-1], divided by the piece count -- except for the LAST
+    word of the caption when it is split (the walk only divides when another word follows: summed, not averaged); when
+    no word is split the reference returns map[3:-1][:C] untouched."""
+    g = maps[3:-1]
+    out = np.zeros((len(spans),) + g.shape[1:], dtype=np.float32)
+    for c, (p, q) in enumerate(spans):
+        acc = g[p].copy()
+        for t in range(p + 1, q):
+            acc = (acc + g[t]).astype(np.float32)
+        if q - p > 1 and c + 1 < len(spans):
+            acc = (acc / np.float32(q - p)).astype(np.float32)
+        out[c] = acc
+    return out
+
+
+def test_merge_plan_on_real_tokenizer_splits_of_dataset_class_names():
+    """Word-piece splits as a real BertTokenizer produces them (tokenizer_cases.json: `pottedplant`, `tvmonitor`,
+    `bedclothes`, ... split into up to a dozen `##` pieces) through host.merge_plan, against the word-level statement of
+    the reference's merge above AND the oracle's token walk -- the cases the tiny synthetic vocabulary of the other
+    fixtures only touches with two words.  (The device kernel is fed these plans: GPU twin in test_hip_parity.py.)"""
+    from oracle import pipeline_np as OP
+    rng = np.random.default_rng(7)
+    n_split_words = 0
+    for i, pieces, words, spans in wordpiece_merge_cases():
+        C = len(words)
+        plan = host.merge_plan(pieces, C)
+        maps = rng.random((3 + len(pieces) + 1, 5, 5), dtype=np.float32)
+        want = expected_word_merge(maps, spans)
+        got = np.zeros_like(want)
+        for c, (toks, div) in enumerate(plan):
+            acc = maps[3:-1][toks[0]].copy()
+            for t in toks[1:]:
+                acc = (acc + maps[3:-1][t]).astype(np.float32)
+            got[c] = acc if div == 1 else (acc / np.float32(div)).astype(np.float32)
+        np.testing.assert_array_equal(got, want, err_msg=f"caption {i}")
+        np.testing.assert_array_equal(OP.merge_tokens(maps, pieces, C), want, err_msg=f"oracle, caption {i}")
+        for c, (p, q) in enumerate(spans):
+            assert plan[c][0] == list(range(p, q))
+            n_split_words += q - p > 1
+    assert n_split_words >= 140                                   # the fixture really is about split words (149 of 267)

@@ -3,6 +3,7 @@
 export TMPDIR=/tmp
 R=$PWD
 cd /tmp; rm -rf /tmp/tp
+mkdir -p $R/gpurun_out
 rocprofv3 --kernel-trace -d /tmp/tp -o tr --output-format csv -- python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-other-modes --no-other-configs --no-noise12 > /tmp/tp.log 2>&1
 f=$(find /tmp/tp -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $R/gpurun_out/trace_pipelined.txt <<'PY'
@@ -13,8 +14,15 @@ rows.sort()
 # two steps are cut off either end
 hist = [(e, q) for s, e, n, q in rows if "hist_kernel" in n]
 piped = [i for i in range(len(hist) - 5) if len(set(q for _, q in hist[i:i + 6])) >= 3]
-t_lo, t_hi = hist[piped[0] + 4][0], hist[piped[-1] + 1][0]
+if piped and piped[0] + 4 < len(hist):
+    t_lo, t_hi = hist[piped[0] + 4][0], hist[piped[-1] + 1][0]
+else:       # fewer than three queues overlap (--pipelines 1, or a short trace): the middle 60 % of the trace
+    print("no pipelined region found (fewer than three queues overlap): using the middle 60 % of the trace")
+    t0, t1 = rows[0][0], rows[-1][1]
+    t_lo, t_hi = t0 + (t1 - t0) // 5, t1 - (t1 - t0) // 5
 sel = [r for r in rows if r[0] >= t_lo and r[1] <= t_hi]
+if not sel:
+    sys.exit("empty selection: trace too short")
 span = (sel[-1][1] - sel[0][0]) / 1e6
 tot = sum(e - s for s, e, _, _ in sel) / 1e6
 busy_end = sel[0][0]; idle = 0
