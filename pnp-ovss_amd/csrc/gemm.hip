@@ -17,25 +17,9 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "gemm_wide.h"
 
 namespace pnp {
-
-// ---- tile rasterisation.  Blocks b and b+8 share an XCD (round-robin dispatch), so each XCD gets
-// a contiguous run of tile ids; inside the run tiles are walked in groups of GM row-tiles x all
-// column tiles, column-major inside the group, so the ~32 workgroups resident on one XCD cover a
-// GM x (32/GM) patch: they share GM A-panels and 32/GM B-panels out of the 4 MB L2 instead of
-// streaming 32 different A-panels from Infinity Cache / HBM.
-template <int GM>
-__device__ __forceinline__ void tile_coords(int bid, int nbm, int nbn, int& bm, int& bn) {
-    const int nwg = nbm * nbn;
-    const int qd = nwg >> 3, rm = nwg & 7, x = bid & 7, i = bid >> 3;
-    const int id = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + i;
-    const int per_group = GM * nbn;
-    const int rg = id / per_group, rem = id - rg * per_group;
-    const int rows = (nbm - rg * GM) < GM ? (nbm - rg * GM) : GM;
-    bn = rem / rows;
-    bm = rg * GM + (rem - bn * rows);
-}
 
 // ---- shared epilogue: one fragment = row m, 4 consecutive columns n..n+3
 struct RowCtx {
@@ -128,8 +112,6 @@ __device__ __forceinline__ void store_frag(const GemmArgs& g, const RowCtx& rc, 
 // ring so two k-slabs are always in flight; one raw s_barrier per k-slab with a COUNTED vmcnt
 // (never 0 in the main loop).  The LDS image is lane-linear per DMA (8 rows x 128 B), so the XOR
 // swizzle is applied to the per-lane SOURCE address and again on the fragment read.
-#define PNP_WAIT_VM_LGKM(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
-#define PNP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // BM x BN block tile, (BM/WTM) x (BN/WTN) waves of WTM x WTN, NS-slot LDS ring.
 template <typename T, int BM, int BN, int WTM, int WTN, int NS, bool PIPE = true>
@@ -391,11 +373,6 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 // issues 48 MFMAs on 24 fragment reads and 8 DMA pieces (the three-sweep form this replaces moved every hi slab twice: 6
 // operand slabs per k-step where 4 suffice, and paid the barrier / hand-over three times).
 //      7 = +bias -> split bf16 pair
-enum { WIDE_BF16 = 0, WIDE_GELU_BF16 = 1, WIDE_RESID_F32 = 2, WIDE_TOKCOLS_BF16 = 3, WIDE_BIAS_F32 = 4, WIDE_TOKCOLS_F32 = 5,
-       WIDE_GELU_SPLIT = 6, WIDE_SPLIT = 7 };
-constexpr int kWideStageRow = 68;                                  // floats per staged row (64 + 4 pad)
-constexpr int kWideStageBytes = 8 * 32 * kWideStageRow * 4;        // 8 waves x 32 rows
-constexpr int kWideSmem = 65536 + kWideStageBytes;                 // slot 0 | slot 1 overlaid by the staging area
 
 template <int EPI, bool X3>
 __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
@@ -1481,6 +1458,12 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     if (x3) {
         if (wide < 0) return PNP_ERR_ARG;
         g.N = (g.Nvalid + 255) / 256 * 256;
+#ifdef PNP_DEV
+        if (!dev_env("PNP_X3_OLD", 0)) r = launch_x3_wide(wide, g, s); else
+#else
+        r = launch_x3_wide(wide, g, s);
+        if (false)
+#endif
         r = wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32, true>(g, s)
             : wide == WIDE_BIAS_F32 ? launch_wide<WIDE_BIAS_F32, true>(g, s)
             : wide == WIDE_GELU_SPLIT ? launch_wide<WIDE_GELU_SPLIT, true>(g, s)

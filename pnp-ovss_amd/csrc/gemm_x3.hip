@@ -1,0 +1,496 @@
+// Split-bf16 ("bf16x3") wide GEMM for gfx950:  C[M,N] = A[M,K] * B[N,K]^T with both operands given as (hi, lo) bf16 pairs
+// (a = a_hi + a_lo), every product accumulated as a_hi.b_lo + a_lo.b_hi + a_hi.b_hi on the bf16 MFMA in fp32: an fp32-class
+// result (2^-16 per product) at a third of the bf16 MFMA rate, ~5x the fp32 MFMA rate.  These are the launches the
+// benchmarked mode spends most of its time in: every Linear of the ViT block (B/vit.py:93-117 qkv / proj, :45-51 fc1 / fc2)
+// and the cross-attention K / V projections of all text layers (B/med.py:208-211) at M = B * N_img rows.
+//
+// Same frame as gemm_nt_wide_kernel (gemm.hip): PERSISTENT 256 x 256 tiles, one 512-thread workgroup per CU, 8 waves (2 x 4)
+// of 128 x 64, operands streamed global -> LDS by `global_load_lds_dwordx4` into a two-slot ring of 32-deep k-slabs
+// (slot = A_hi | A_lo | B_hi | B_lo, 256 rows x 64 bytes each), ONE s_barrier per slab, slab 0 of the next tile requested
+// before the epilogue, epilogues staged through LDS so that every global access is a full line.
+//
+// What is different (round 4): the matrix instruction is v_mfma_f32_16x16x32_bf16 instead of 32x32x16.  At equal FLOPs and
+// equal cycles per FLOP the chip holds a higher clock on the 16x16x32 form (MI355X_MICROARCH.md, DVFS give-back (7): 1.12-1.15x
+// in a bare loop; a timing-only swap of the opcode in the 32x32 kernel ran 5-7 % faster on every ViT shape), but hipcc does
+// not keep 4-register accumulators in place across a builtin MFMA chain (round 1: copies and spills made the port slower
+// than what it replaced).  So the MFMAs of one 16-row m-tile -- 4 n-tiles x 3 products = 12 instructions -- are ONE
+// `asm volatile` block whose accumulators are tied in/out operands ("+v"): in place by construction, issued back to back,
+// and a fixed point of the schedule: the fragment reads and DMA pieces the compiler emits stay between the blocks where
+// the source puts them.  The compiler still tracks every LDS read (its counted lgkmcnt waits in front of each block).
+//   per slab and wave: 8 blocks (m-tiles) x 12 MFMAs; the A fragments (hi, lo) of m-tile j+3 are read behind block j into
+//   a 4-slot rotation, the B fragments of the NEXT slab (4 n-tiles x (hi, lo)) behind the slab hand-over into the other of
+//   two register sets; the hand-over (own reads done, own DMA pieces of slab t+1 landed, s_barrier) sits behind block 5; the
+//   8 DMA pieces of slab t+2 are issued two per block behind blocks 5, 6 and blocks 0, 1 of the next slab.
+//   registers: 128 accumulators + 64 B fragments + 32 A fragments + addresses.
+// LDS image: 16-byte chunks swizzled chunk ^= (-(row >> 2)) & 3, so the 16 lanes a ds_read_b128 services together (4 rows of
+// one chunk column and 8 + 4 rows of the next) hit 16 different 16-byte slots of the 256-byte bank row; applied to the
+// per-lane SOURCE address of the DMA pieces and again on the fragment reads.
+// Accumulator layout (operands swapped at the MFMA, D = Btile * Atile^T): lane (r = l & 15, q = l >> 4) of tile (jm, in)
+// owns row m = 16 jm + r and the 4 consecutive columns n = 16 in + 4 q .. + 3.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "gemm.h"
+#include "gemm_wide.h"
+
+namespace pnp {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t frag16;      // one lane's 8 bf16 of a 16x16x32 operand
+
+// 6 MFMAs of one m-tile and two n-tiles: c[i] += bl[i].ah + bh[i].al + bh[i].ah (small terms first), accumulators in place
+__device__ __forceinline__ void x3_half(f32x4& c0, f32x4& c1, const frag16& ah, const frag16& al, const frag16& bh0, const frag16& bh1,
+                                        const frag16& bl0, const frag16& bl1) {
+    asm volatile(
+        "v_mfma_f32_16x16x32_bf16 %0, %6, %2, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %7, %2, %1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %4, %3, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %5, %3, %1\n\t"
+        "v_mfma_f32_16x16x32_bf16 %0, %4, %2, %0\n\t"
+        "v_mfma_f32_16x16x32_bf16 %1, %5, %2, %1"
+        : "+v"(c0), "+v"(c1)
+        : "v"(ah), "v"(al), "v"(bh0), "v"(bh1), "v"(bl0), "v"(bl1));
+}
+
+// EPI: WIDE_RESID_F32 (+bias +residual -> fp32) | WIDE_BIAS_F32 (+bias -> fp32) | WIDE_TOKCOLS_F32 (per-row bias, token columns
+// remapped to per-image padded columns -> fp32) | WIDE_GELU_SPLIT (+bias, erf-GELU -> (hi, lo) bf16 pair) | WIDE_SPLIT (+bias -> pair)
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 256, SLOT = 65536, ARR = 16384;
+    constexpr int JM = 8, IN = 4;                   // 16 x 16 tiles per wave: 128 (m) x 64 (n)
+    constexpr int NDMA = 8;
+    constexpr int kDrain = (EPI == WIDE_GELU_SPLIT || EPI == WIDE_SPLIT) ? 32 : 24;
+    constexpr int SROW = kWideStageRow;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
+    const int ntiles = nbm * nbn;
+    const int nk = g.K / 32;                        // even, >= 2 (gemm_nt: K % 64 == 0)
+    const char* Ab = reinterpret_cast<const char*>(g.A);
+    const char* Bb = reinterpret_cast<const char*>(g.B);
+    const char* Alo = reinterpret_cast<const char*>(g.A_lo);
+    const char* Blo = reinterpret_cast<const char*>(g.B_lo);
+
+    // DMA piece = 16 rows of ONE array (uniform base, per-lane 32-bit offset): a wave's hi and lo piece of the same rows
+    // share an offset.  Lane l lands at row l >> 2, physical chunk l & 3 of the piece.
+    uint32_t soff[4];
+    auto set_tile = [&](int tile, int& m0, int& n0, int lane) {
+        int bm, bn;
+        tile_coords<4>(tile, nbm, nbn, bm, bn);
+        m0 = bm * BM;
+        n0 = bn * BN;
+        const uint32_t lda_b = (uint32_t)g.lda * 2, ldb_b = (uint32_t)g.ldb * 2;
+        const int c = (lane & 3) ^ ((-(lane >> 4)) & 3);     // logical chunk this lane's 16 bytes land as (row & 15 = lane >> 2)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {                        // two 16-row groups per wave and operand
+            const int row = (wave * 2 + i) * 16 + (lane >> 2);
+            int gr = m0 + row;
+            gr = gr < g.M ? gr : g.M - 1;
+            soff[i] = (uint32_t)gr * lda_b + c * 16;
+            gr = n0 + row;
+            gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
+            soff[2 + i] = (uint32_t)gr * ldb_b + c * 16;
+        }
+    };
+    // on = non-zero / zero (wave-uniform): a piece issued under EXEC = 0 moves nothing, so the slabs at either end of the
+    // k range run the SAME instruction stream as the steady state (no peeled copies of the slab body whose register
+    // assignment the allocator then has to reconcile with the loop's through scratch memory)
+    auto issue_one = [&](int kt, int i, uint32_t on) {  // piece i: operand = i >> 2, row group = (i >> 1) & 1, array (hi | lo) = i & 1
+#ifdef PNP_X3_ABLATE                                // timing-only builds (results are garbage; tools/gemm_x3_ab.py): 1 = no steady-state
+        if (kt >= 2) return;                        // DMA, 3 = also no slab barrier, 4 = also no fragment reads.  Compile-time:
+#endif                                              // a run-time test inside the slab loop changes the schedule it is meant to time
+        const int op = i >> 2, rg = (i >> 1) & 1, lo = i & 1;
+        const char* base = op ? (lo ? Blo : Bb) : (lo ? Alo : Ab);
+        const int d = (kt & 1) * SLOT + op * (2 * ARR) + lo * ARR + (wave * 2 + rg) * 1024;
+        // LDS-DMA as inline asm, not as __builtin_amdgcn_global_load_lds: hipcc treats the builtin like a FLAT access that
+        // may touch both memories, and while one is pending every wait it inserts for an LDS read is forced to lgkmcnt(0)
+        // (SIInsertWaitcnts "pending flat") -- i.e. a fragment read issued right before an MFMA block would be waited for
+        // there.  Hidden from the compiler, its ds_read waits are counted (only the fragments a block consumes), and the
+        // landing of the pieces is covered by the explicit vmcnt(0) in front of each slab's barrier.
+        const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + d);
+        // the per-lane source offset is formed inside the block (one dead temporary) so that the compiler cannot hoist the
+        // eight adds of a slab to the top of the loop and hold their results in registers the accumulators need
+        uint32_t voff;
+        uint64_t saved;
+        asm volatile(
+            "s_mov_b64 %1, exec\n\t"
+            "s_cmp_lg_u32 %6, 0\n\t"
+            "s_cselect_b64 exec, exec, 0\n\t"
+            "v_add_u32 %0, %3, %2\n\t"
+            "s_mov_b32 m0, %5\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %0, %4\n\t"
+            "s_mov_b64 exec, %1"
+            : "=&v"(voff), "=&s"(saved)
+            : "v"(soff[op * 2 + rg]), "s"((uint32_t)kt * 64), "s"(base), "s"(lds), "s"(on)
+            : "memory", "scc");        // (m0 is reserved: nothing else in this kernel uses it)
+    };
+    auto stamp = [&](int slot) {
+        if (g.stamps && tid == 0) {
+            g.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
+            g.stamps[(size_t)blockIdx.x * 8 + 4 + slot] = wall_clock64();
+        }
+    };
+
+    // fragment addresses: row = tile row + r, logical chunk q; the swizzle term depends on r only (tile rows are multiples of 16)
+    const int fo = r * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4);
+    // one base register per (operand, ring slot); everything else of a fragment address fits the 16-bit offset field of
+    // ds_read_b128.  The slot-1 bases are made opaque to the compiler: folded into constants they exceed that field and it
+    // materialises a separate address register per read (20 registers that the accumulators need)
+    int fa_off[2], fb_off[2];
+    fa_off[0] = wm * (128 * 64) + fo;                                   // A_hi (lo: + ARR)
+    fb_off[0] = 2 * ARR + wn * (64 * 64) + fo;                          // B_hi
+    fa_off[1] = fa_off[0] + SLOT;
+    fb_off[1] = fb_off[0] + SLOT;
+    asm volatile("" : "+v"(fa_off[1]), "+v"(fb_off[1]));
+    float* const stg = reinterpret_cast<float*>(smem + SLOT) + wave * (32 * SROW);
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int m0, n0;
+    bool drain32 = false;                           // the previous tile's epilogue left >= kDrain stores behind this tile's slab 0
+    stamp(0);
+    set_tile(tile, m0, n0, lane);
+#pragma unroll
+    for (int i = 0; i < NDMA; i++) issue_one(0, i, 1u);
+
+    for (;;) {
+        f32x4 acc[JM][IN];
+#pragma unroll
+        for (int j = 0; j < JM; j++)
+#pragma unroll
+            for (int i = 0; i < IN; i++) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        frag16 ah[4], al[4], bh[2][IN], bl[2][IN];
+        auto rd_a = [&](int slot, int s, int jm) {
+#if defined(PNP_X3_ABLATE) && PNP_X3_ABLATE >= 4
+            return;
+#endif
+            const char* p = smem + fa_off[s] + jm * 1024;
+            ah[slot] = *reinterpret_cast<const frag16*>(p);
+            al[slot] = *reinterpret_cast<const frag16*>(p + ARR);
+        };
+        auto rd_b = [&](int set, int s, int in) {
+#if defined(PNP_X3_ABLATE) && PNP_X3_ABLATE >= 4
+            return;
+#endif
+            const char* p = smem + fb_off[s] + in * 1024;
+            bh[set][in] = *reinterpret_cast<const frag16*>(p);
+            bl[set][in] = *reinterpret_cast<const frag16*>(p + ARR);
+        };
+
+        // slab 0 of this tile is in flight (requested during the previous tile's epilogue, or above).  vmcnt counts in issue
+        // order, so after a full-tile epilogue that issued >= kDrain stores behind the DMA pieces, "at most kDrain outstanding"
+        // already means the slab has landed and the rest of those stores drain under the first blocks of this tile.  The
+        // pieces are requested behind quarter 0 of the fp32 epilogues (24 stores follow) and in front of all 64 stores of the
+        // split ones
+        if (drain32) PNP_WAIT_VM(kDrain);
+        else PNP_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();               // slab 0 complete; staging area (slot 1) no longer read
+#pragma unroll
+        for (int i = 0; i < NDMA; i++) issue_one(1, i, 1u);
+        rd_a(0, 0, 0);
+        rd_a(1, 0, 1);
+        rd_a(2, 0, 2);
+#pragma unroll
+        for (int i = 0; i < IN; i++) rd_b(0, 0, i);
+
+        // one slab; S = its ring slot / B register set (compile-time).  16 half blocks (j, h) = 6 MFMAs on m-tile j, n-tiles
+        // 2h, 2h+1, each followed by a small cluster:
+        //   (j, 0), j <= 4 : A(j + 3)                       (0,0) (0,1) (1,0) (1,1): + pieces 4..7 of slab kt + 1 ("head")
+        //   (5, 0)         : hand-over, A'(0), piece 0 of slab kt + 2 ("tail")
+        //   (5, 1)         : B'(0), piece 1      (6,0): A'(1) B'(1), piece 2      (6,1): B'(2), piece 3      (7,0): A'(2) B'(3)
+        // i.e. at most ONE DMA piece per cluster with six MFMAs of the wave's own between two pieces: a piece holds its wave
+        // for 100+ cycles at issue, and only the SIMD partner's MFMAs can use the matrix pipe meanwhile -- two pieces in a row
+        // outlast the partner's half block.  Every read is at least three half blocks old when its consumer starts (the
+        // compiler's waits are counted); every piece has seven half blocks or more to land.  Slab 1 is requested whole in the
+        // prologue (no head in slab 0); behind the last slab nothing is requested (masks) and the hand-over and the reads of
+        // the "next" slab run on whatever the other slot holds: harmless, and the same code for every slab.
+        auto slab = [&](int kt, auto par) {
+            constexpr int S = decltype(par)::value;
+            const uint32_t head = __builtin_amdgcn_readfirstlane((kt >= 1 && kt + 1 < nk) ? 1 : 0);
+            const uint32_t tail = __builtin_amdgcn_readfirstlane((kt + 2 < nk) ? 1 : 0);
+#pragma unroll
+            for (int j = 0; j < JM; j++) {
+                x3_half(acc[j][0], acc[j][1], ah[j & 3], al[j & 3], bh[S][0], bh[S][1], bl[S][0], bl[S][1]);
+                if (j + 3 < JM) {
+                    rd_a((j + 3) & 3, S, j + 3);
+                    if (j < 2) issue_one(kt + 1, 4 + 2 * j, head);
+                } else {
+                    if (j == JM - 3) {
+                        // own reads of slab kt complete, own pieces of slab kt+1 landed (a builtin, not asm: the compiler's
+                        // scoreboard sees it and adds no wait of its own behind the reads that follow)
+#if !defined(PNP_X3_ABLATE) || PNP_X3_ABLATE < 3
+                        __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+                        __builtin_amdgcn_s_barrier();         // slab kt+1 complete; nobody reads slab kt's slot any more
+#endif
+                    }
+                    rd_a((j + 3) & 3, S ^ 1, j + 3 - JM);
+                    if (j == JM - 2) rd_b(S ^ 1, S ^ 1, 1);
+                    if (j == JM - 1) rd_b(S ^ 1, S ^ 1, 3);
+                    if (j == JM - 3) issue_one(kt + 2, 0, tail);
+                    if (j == JM - 2) issue_one(kt + 2, 2, tail);
+                }
+                x3_half(acc[j][2], acc[j][3], ah[j & 3], al[j & 3], bh[S][2], bh[S][3], bl[S][2], bl[S][3]);
+                if (j < 2) issue_one(kt + 1, 5 + 2 * j, head);
+                if (j == JM - 3) {
+                    rd_b(S ^ 1, S ^ 1, 0);
+                    issue_one(kt + 2, 1, tail);
+                }
+                if (j == JM - 2) {
+                    rd_b(S ^ 1, S ^ 1, 2);
+                    issue_one(kt + 2, 3, tail);
+                }
+            }
+        };
+        constexpr std::integral_constant<int, 0> s0{};
+        constexpr std::integral_constant<int, 1> s1{};
+        for (int kt = 0; kt < nk; kt += 2) {        // nk is even
+            slab(kt, s0);
+            slab(kt + 1, s1);
+        }
+        // the compiler does not see the MFMAs inside the asm blocks: cover the matrix-pipe -> VALU read hazard of the last ones
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        if (tile == (int)blockIdx.x) stamp(2);
+
+        __syncthreads();                            // every wave is done reading the last slab: both slots are free
+        // everything the epilogue derives from the lane id is RE-derived here from an opaque copy of the thread id: computed
+        // once in front of the k loop (where the compiler would otherwise put it) these ~15 values are live across a loop that
+        // has no register to spare, and are spilled around it -- with scratch reloads whose vmcnt waits also wait for the DMA
+        // pieces in flight
+        int etid = tid;
+        asm volatile("" : "+v"(etid));
+        const int lane = etid & 63, r = lane & 15, q = lane >> 4;
+        const int em0 = m0, en0 = n0;
+        // epilogue operands are requested BEFORE the next tile's first slab: vmcnt is one in-order counter, a wait for a
+        // load issued behind the DMA pieces would also wait for those
+        const int n = en0 + wn * 64 + (lane & 15) * 4;          // this lane's 4 output columns on the way out (same for every row)
+        const bool nv = n < g.Nvalid;                           // N is a multiple of 4 on the row-major epilogues
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        f32x4 rv[8];
+        f32x4 bacc[IN];                             // split epilogues: bias in the accumulator layout
+        if constexpr (EPI == WIDE_GELU_SPLIT || EPI == WIDE_SPLIT) {
+#pragma unroll
+            for (int i = 0; i < IN; i++) {
+                const int nn = en0 + wn * 64 + i * 16 + q * 4;
+                bacc[i] = (g.bias && nn < g.Nvalid) ? *reinterpret_cast<const f32x4*>(g.bias + nn) : bv;
+            }
+        }
+        if constexpr (EPI == WIDE_BIAS_F32 || EPI == WIDE_RESID_F32) {
+            if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+        }
+        if constexpr (EPI == WIDE_RESID_F32) {
+            const int mrow0 = em0 + wm * 128 + (lane >> 4);
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int m = mrow0 + it * 4;
+                rv[it] = (m < g.M && nv) ? *reinterpret_cast<const f32x4*>(g.resid + (size_t)m * g.ldr + n) : bv;
+            }
+        }
+        float brow[JM] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // TOKCOLS: bias of this lane's row in each 16-row tile
+        if constexpr (EPI == WIDE_TOKCOLS_F32) {
+#pragma unroll
+            for (int j = 0; j < JM; j++) {
+                const int m = em0 + wm * 128 + j * 16 + r;
+                if (g.bias && m < g.M) brow[j] = g.bias[m];
+            }
+        }
+        const int next = tile + gridDim.x;
+        // slab 0 of the next tile flies during this tile's epilogue.  It is requested right BEHIND the first use of the operands
+        // loaded above (bias, first residual rows): vmcnt is one in-order counter and the compiler does not see the pieces (asm),
+        // so its wait for those loads would count the pieces as landed-before -- issued in front of that wait they would be
+        // waited for with it (~3 us per tile measured); loads issued later wait for the pieces anyway, by then long landed
+        auto request_next = [&]() {
+            if (next < ntiles) {
+                set_tile(next, m0, n0, lane);
+#pragma unroll
+                for (int i = 0; i < NDMA; i++) issue_one(0, i, 1u);
+            }
+        };
+
+        if constexpr (EPI == WIDE_TOKCOLS_F32) {
+            // 32-row quarters staged as fp32 with the row bias added in the accumulator layout; on the way out a lane owns a
+            // PAIR of token columns (8-byte stores, 256 contiguous bytes per row) when col_div is even -- pairs then never
+            // straddle an image -- else single tokens
+            const int l32 = lane & 31, hi = lane >> 5;
+            const bool pairs = (g.col_div & 1) == 0;
+            const int tl0 = pairs ? 2 * l32 : lane;
+            const int tok = en0 + wn * 64 + tl0;
+            size_t ocol = tok;
+            if (g.col_div > 0) {
+                const int b = tok / g.col_div;
+                const int tl = tok - b * g.col_div;
+                ocol = (size_t)b * g.col_pad + tl;
+            }
+            float* const ocolp = g.out_f32 + ocol;
+            const bool tv = tok < g.Nvalid;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                const int mbase = em0 + wm * 128 + qd * 32;
+#pragma unroll
+                for (int j2 = 0; j2 < 2; j2++)
+#pragma unroll
+                    for (int i = 0; i < IN; i++) {
+                        const float br = brow[qd * 2 + j2];
+                        const f32x4 v = acc[qd * 2 + j2][i] + br;
+                        *reinterpret_cast<f32x4*>(stg + (j2 * 16 + r) * SROW + i * 16 + q * 4) = v;
+                    }
+                if (qd == 0) request_next();
+                if (pairs) {
+                    f32x2 sv[16];
+#pragma unroll
+                    for (int it = 0; it < 16; it++) sv[it] = *reinterpret_cast<const f32x2*>(stg + (it * 2 + hi) * SROW + tl0);
+#pragma unroll
+                    for (int it = 0; it < 16; it++) {
+                        const int m = mbase + it * 2 + hi;
+                        if (tv && m < g.M) *reinterpret_cast<f32x2*>(ocolp + (size_t)m * g.ldo) = sv[it];
+                    }
+                } else {
+#pragma unroll 8
+                    for (int row = 0; row < 32; row++) {
+                        const float v = stg[row * SROW + lane];
+                        if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo] = v;
+                    }
+                }
+            }
+        } else if constexpr (EPI == WIDE_GELU_SPLIT || EPI == WIDE_SPLIT) {
+            // per 64-row half: bias (+ erf-form GELU, |erf error| <= 1.5e-7) in the accumulator layout, then two passes over a
+            // bf16 staging of the half: hi = bf16(v) -> out_t, lo = bf16(v - hi) -> out_lo (the pair carries 16 significant
+            // bits of v).  Half-outer order: the stores of half 0 drain while the GELU of half 1 runs on the VALU.
+            constexpr int HROW = 68;                // bf16 per staged row (64 + 4 pad)
+            bf16* const stgh = reinterpret_cast<bf16*>(smem + SLOT) + wave * (64 * HROW);
+            const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+#pragma unroll
+                for (int j4 = 0; j4 < 4; j4++)
+#pragma unroll
+                    for (int i = 0; i < IN; i++)
+#pragma unroll
+                        for (int e = 0; e < 4; e += 2) {
+                            f32x4& a = acc[half * 4 + j4][i];
+                            pnp_f32x2 v = {a[e] + bacc[i][e], a[e + 1] + bacc[i][e + 1]};
+                            if constexpr (EPI == WIDE_GELU_SPLIT) v = gelu_erf_fast2(v);
+                            a[e] = v[0];
+                            a[e + 1] = v[1];
+                        }
+                if (half == 0) request_next();
+#pragma unroll
+                for (int part = 0; part < 2; part++) {
+                    bf16* const obase = reinterpret_cast<bf16*>(part ? g.out_lo : g.out_t) + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo_t + n;
+#pragma unroll
+                    for (int j4 = 0; j4 < 4; j4++)
+#pragma unroll
+                        for (int i = 0; i < IN; i++) {
+                            const f32x4& a = acc[half * 4 + j4][i];
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; e++) {
+                                const float v = a[e];
+                                const bf16 h = (bf16)v;
+                                pk[e] = part ? (bf16)(v - (float)h) : h;
+                            }
+                            *reinterpret_cast<bf16x4*>(stgh + (j4 * 16 + r) * HROW + i * 16 + q * 4) = pk;
+                        }
+                    bf16x4 sv[16];
+#pragma unroll
+                    for (int it = 0; it < 16; it++)
+                        sv[it] = *reinterpret_cast<const bf16x4*>(stgh + (it * 4 + (lane >> 4)) * HROW + (lane & 15) * 4);
+#pragma unroll
+                    for (int it = 0; it < 16; it++) {
+                        const int m = em0 + wm * 128 + half * 64 + it * 4 + (lane >> 4);
+                        if (full || (m < g.M && nv)) *reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t) = sv[it];
+                    }
+                }
+            }
+        } else {
+            // fp32 residual / bias epilogue, 32-row quarters staged as fp32.  The residual rows of quarter q+1 are requested
+            // before the stores of quarter q (two register sets), so each wait has a whole quarter of work in front of it
+            // and never sits behind a store.
+            constexpr bool kResid = EPI == WIDE_RESID_F32;
+            const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+            const float* const rbase = kResid ? g.resid + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldr + n : nullptr;
+            float* const obase = g.out_f32 + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo + n;
+            f32x4 rw[8];
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++) {
+                f32x4* const rcur = (qd & 1) ? rw : rv;
+                f32x4* const rnxt = (qd & 1) ? rv : rw;
+#pragma unroll
+                for (int j2 = 0; j2 < 2; j2++)
+#pragma unroll
+                    for (int i = 0; i < IN; i++)
+                        *reinterpret_cast<f32x4*>(stg + (j2 * 16 + r) * SROW + i * 16 + q * 4) = acc[qd * 2 + j2][i];
+                if (kResid && qd < 3) {
+#pragma unroll
+                    for (int it = 0; it < 8; it++) {
+                        const int m = em0 + wm * 128 + (qd + 1) * 32 + it * 4 + (lane >> 4);
+                        rnxt[it] = (full || (m < g.M && nv)) ? *reinterpret_cast<const f32x4*>(rbase + (size_t)((qd + 1) * 32 + it * 4) * g.ldr) : bv;
+                    }
+                }
+                f32x4 sv[8];                        // all LDS reads of the quarter in flight before the first use
+#pragma unroll
+                for (int it = 0; it < 8; it++)
+                    sv[it] = *reinterpret_cast<const f32x4*>(stg + (it * 4 + (lane >> 4)) * SROW + (lane & 15) * 4);
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    f32x4 v = sv[it] + bv;
+                    if constexpr (kResid) v += rcur[it];
+                    const int m = em0 + wm * 128 + qd * 32 + it * 4 + (lane >> 4);
+                    if (full || (m < g.M && nv)) *reinterpret_cast<f32x4*>(obase + (size_t)(qd * 32 + it * 4) * g.ldo) = v;
+                }
+                if (qd == 0) request_next();
+            }
+        }
+        if (tile == (int)blockIdx.x) stamp(1);     // diagnostics: first tile's epilogue done (stores issued)
+        if (next >= ntiles) break;
+        tile = next;
+        // every lane of a full tile executes all of the epilogue's stores (8 per quarter and wave, 64 for the split pair)
+        drain32 = (EPI != WIDE_TOKCOLS_F32) && (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+    }
+    if (g.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);                                   // whole workgroup (all its tiles) done
+    }
+}
+
+template <int EPI>
+static int launch_x3(const GemmArgs& g, hipStream_t s) {
+    const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
+    static const int n_cu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    if (!n_cu) return PNP_ERR_HIP;
+    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_x3_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideSmem);
+    if (attr != hipSuccess) return PNP_ERR_HIP;
+    const int ntiles = nbm * nbn;
+    int cap = n_cu;
+#ifdef PNP_DEV
+    if (getenv("PNP_GEMM_GRID")) cap = atoi(getenv("PNP_GEMM_GRID"));
+#endif
+    const int grid = ntiles > cap ? cap : ntiles;        // one workgroup per CU (LDS-limited) walks the tiles
+    hipLaunchKernelGGL((gemm_nt_x3_kernel<EPI>), dim3(grid), dim3(512), kWideSmem, s, g);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+int launch_x3_wide(int epi, const GemmArgs& g, hipStream_t s) {
+    switch (epi) {
+        case WIDE_RESID_F32: return launch_x3<WIDE_RESID_F32>(g, s);
+        case WIDE_BIAS_F32: return launch_x3<WIDE_BIAS_F32>(g, s);
+        case WIDE_GELU_SPLIT: return launch_x3<WIDE_GELU_SPLIT>(g, s);
+        case WIDE_SPLIT: return launch_x3<WIDE_SPLIT>(g, s);
+        case WIDE_TOKCOLS_F32: return launch_x3<WIDE_TOKCOLS_F32>(g, s);
+    }
+    return PNP_ERR_ARG;
+}
+
+}  // namespace pnp
