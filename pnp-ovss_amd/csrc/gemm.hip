@@ -1410,6 +1410,7 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
 #ifdef PNP_DEV
     variant = dev_env("PNP_GEMM_VARIANT", 0);              // 1 / 2 / 3 / 4: generic 256x128 / generic 256x256 / generic 128x128 / wide
     g.ablate = dev_env("PNP_GEMM_ABLATE", 0);
+    if (getenv("PNP_GEMM_GM")) g.ablate = 100 + dev_env("PNP_GEMM_GM", 4);   // tile-order experiment (gemm_x3.hip)
     if (dev_env("PNP_GEMM_STAMPS", 0)) {
         if (!stamp_buf() && hipMalloc(&stamp_buf(), kStampBlocks * 64) != hipSuccess) return PNP_ERR_HIP;
         g.stamps = stamp_buf();

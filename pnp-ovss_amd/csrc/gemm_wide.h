@@ -23,6 +23,18 @@ __device__ __forceinline__ void tile_coords(int bid, int nbm, int nbn, int& bm, 
     bm = rg * GM + (rem - bn * rows);
 }
 
+// the same with the group height as a run-time value (DEV builds: the tile-order experiment of tools/gemm_window_traffic.sh)
+__device__ __forceinline__ void tile_coords_rt(int gm, int bid, int nbm, int nbn, int& bm, int& bn) {
+    const int nwg = nbm * nbn;
+    const int qd = nwg >> 3, rm = nwg & 7, x = bid & 7, i = bid >> 3;
+    const int id = (x < rm ? x * (qd + 1) : rm * (qd + 1) + (x - rm) * qd) + i;
+    const int per_group = gm * nbn;
+    const int rg = id / per_group, rem = id - rg * per_group;
+    const int rows = (nbm - rg * gm) < gm ? (nbm - rg * gm) : gm;
+    bn = rem / rows;
+    bm = rg * gm + (rem - bn * rows);
+}
+
 #define PNP_WAIT_VM_LGKM(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
 #define PNP_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 

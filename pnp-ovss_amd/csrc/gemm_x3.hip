@@ -81,6 +81,16 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
     uint32_t soff[4];
     auto set_tile = [&](int tile, int& m0, int& n0, int lane) {
         int bm, bn;
+#ifdef PNP_DEV
+        if (g.ablate >= 100) {                               // PNP_GEMM_GM: group height of the tile order (0 = plain row-major ids)
+            if (g.ablate == 100) {
+                bm = tile / nbn;
+                bn = tile - bm * nbn;
+            } else {
+                tile_coords_rt(g.ablate - 100, tile, nbm, nbn, bm, bn);
+            }
+        } else
+#endif
         tile_coords<4>(tile, nbm, nbn, bm, bn);
         m0 = bm * BM;
         n0 = bn * BN;

@@ -489,8 +489,18 @@ __global__ __launch_bounds__(768) void vit_attn32_x3_kernel(const bf16* __restri
             int lr = rs + prow;
             lr = (lr < N ? lr : N - 1) - rs;
             const uint32_t loff = (uint32_t)lr * ld2 + ((p & 1) ? sc_odd : sc_even);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + loff),
-                                             (__attribute__((address_space(3))) void*)(ring[t & 1] + p * 1024), 16, 0, 0);
+            // LDS-DMA as inline asm (round 4): hipcc models __builtin_amdgcn_global_load_lds as a FLAT access that may touch
+            // both memories, and while one is pending EVERY wait it inserts for an LDS read is forced to lgkmcnt(0)
+            // (SIInsertWaitcnts "pending flat") -- with a tile always in flight that is every wait of this loop: each K / V
+            // fragment read was waited for right where it was issued.  Hidden from the compiler its LDS waits are counted;
+            // the landing of the pieces is covered by the explicit vmcnt(0) in front of the tile barrier.
+            const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(ring[t & 1] + p * 1024);
+            const uint64_t sb = reinterpret_cast<uint64_t>(sbase);           // uniform; made scalar explicitly for the "s" operand
+            const uint64_t sbu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sb);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(loff), "s"(sbu),
+                         "s"(__builtin_amdgcn_readfirstlane((int)lds))
+                         : "memory");
         }
     };
 
