@@ -482,8 +482,8 @@ def run_rank(a):
         kern = {"bf16": "gemm_nt_wide_kernel (persistent 256x256 bf16 LDS-DMA ring GEMM, 32x32x16 MFMA; all launches with "
                         "M = B*N rows timed)",
                 "f32": "gemm_nt_big_kernel<float> (128x128 fp32 LDS-DMA ring GEMM, 16x16x4 MFMA)",
-                "bf16x3": "gemm_nt_wide_kernel<.., X3> (persistent 256x256 split-bf16 GEMM: one K sweep over (hi, lo) operand "
-                          "pairs, three 32x32x16 bf16 MFMAs per fragment pair; `achieved` counts ALGORITHMIC flops 2MNK, the MFMA "
+                "bf16x3": "gemm_nt_x3_kernel (persistent 256x256 split-bf16 GEMM: one K sweep over (hi, lo) operand pairs, three "
+                          "v_mfma_f32_16x16x32_bf16 per fragment pair; `achieved` counts ALGORITHMIC flops 2MNK, the MFMA "
                           "work issued is 3x that, so the ceiling of frac is 1/3; issued_frac = 3 x frac)"}[dtype]
         out = {"bound": "mfma", "kernel": kern,
                "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -507,8 +507,8 @@ def run_rank(a):
     def traffic_for(dtype):
         """HBM-side bytes per launch of the dense GEMM family from the committed rocprofv3 PMC passes (FETCH_SIZE /
         WRITE_SIZE cannot be read live; see profiles/*_gemm_traffic*.json)."""
-        names = {"bf16": ("r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"),
-                 "bf16x3": ("r03_gemm_traffic_bf16x3.json",)}.get(dtype, ())
+        names = {"bf16": ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"),
+                 "bf16x3": ("r04_gemm_traffic_bf16x3.json", "r03_gemm_traffic_bf16x3.json")}.get(dtype, ())
         for tf in names:
             tf = os.path.join(ROOT, "profiles", tf)
             if os.path.exists(tf):

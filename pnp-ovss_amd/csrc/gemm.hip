@@ -364,17 +364,9 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
 
 // EPI: 0 = +bias -> bf16 | 1 = +bias, GELU -> bf16 | 2 = +bias +residual -> fp32 |
 //      3 = +per-row bias, token columns remapped to per-image padded columns -> bf16 (transposed cross-attention K / V)
-//      4 = +bias -> fp32 | 5 = as 3 with fp32 output | 6 = +bias, GELU (erf form) -> split bf16 pair (hi, lo)
-// X3 (split-bf16, "bf16x3"): the operands are bf16 pairs a = a_hi + a_lo, b = b_hi + b_lo and every k16 sub-step issues
-// three MFMAs per fragment pair -- (a_hi, b_lo), (a_lo, b_hi), (a_hi, b_hi) -- into the same fp32 accumulator: an fp32-class
-// product (terms dropped: a_lo.b_lo, 2^-18 relative, and what two bf16 cannot hold of an fp32 operand, 2^-17) at a third of
-// the bf16 MFMA rate, i.e. ~5x the fp32 MFMA rate (v_mfma_f32_16x16x4_f32 runs at 1/16 of bf16).  ONE sweep over K: a ring
-// slot holds a 32-deep k-slab of all four arrays (A_hi | A_lo | B_hi | B_lo, 256 rows x 64 bytes each); per slab a wave
-// issues 48 MFMAs on 24 fragment reads and 8 DMA pieces (the three-sweep form this replaces moved every hi slab twice: 6
-// operand slabs per k-step where 4 suffice, and paid the barrier / hand-over three times).
-//      7 = +bias -> split bf16 pair
-
-template <int EPI, bool X3>
+// The split-bf16 ("bf16x3") launches of the same tile frame, and their fp32-facing epilogues (4 = +bias -> fp32 | 5 = as 3 with
+// fp32 output | 6 = +bias, erf-GELU -> (hi, lo) bf16 pair | 7 = +bias -> pair), live in gemm_x3.hip (v_mfma_f32_16x16x32_bf16).
+template <int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, ROWB = 128, BK = 64, STAGE = (BM + BN) * ROWB;
     constexpr int TM = 4, TN = 2;                   // 32 x 32 tiles per wave: 128 (m) x 64 (n)
@@ -388,36 +380,18 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
     const int wm = wave >> 2, wn = wave & 3;
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const int ntiles = nbm * nbn;
-    // X3: a slab is 32 k-values of the hi AND the lo array of each operand.  Slot image: four 16 KB arrays
-    // A_hi | A_lo | B_hi | B_lo of 256 rows x 64 bytes (4 chunks of 16 B, chunk ^= (row >> 2) & 3: the 16 lanes a
-    // ds_read_b128 services together hit 16 different 16-byte slots of the 256-byte bank row).  A DMA piece is 16 rows
-    // of ONE array (uniform base, per-lane 32-bit offset), so a wave's hi and lo piece of the same rows share an offset.
-    const int nk = X3 ? g.K / 32 : g.K / BK;
+    const int nk = g.K / BK;
     const char* Ab = reinterpret_cast<const char*>(g.A);
     const char* Bb = reinterpret_cast<const char*>(g.B);
-    const char* Alo = reinterpret_cast<const char*>(g.A_lo);
-    const char* Blo = reinterpret_cast<const char*>(g.B_lo);
 
-    uint32_t soff[X3 ? 4 : NDMA];
+    uint32_t soff[NDMA];
     auto set_tile = [&](int tile, int& m0, int& n0) {
         int bm, bn;
         tile_coords<4>(tile, nbm, nbn, bm, bn);
         m0 = bm * BM;
         n0 = bn * BN;
         const uint32_t lda_b = (uint32_t)g.lda * 2, ldb_b = (uint32_t)g.ldb * 2;
-        if constexpr (X3) {
-#pragma unroll
-            for (int i = 0; i < 2; i++) {                    // two 16-row groups per wave and operand
-                const int row = (wave * 2 + i) * 16 + (lane >> 2);
-                const int c = (lane & 3) ^ ((row >> 2) & 3);    // logical chunk this lane's 16 bytes land as
-                int gr = m0 + row;
-                gr = gr < g.M ? gr : g.M - 1;
-                soff[i] = (uint32_t)gr * lda_b + c * 16;
-                gr = n0 + row;
-                gr = gr < g.Nvalid ? gr : g.Nvalid - 1;
-                soff[2 + i] = (uint32_t)gr * ldb_b + c * 16;
-            }
-        } else {
+        {
             const int pc = lane & 7;
 #pragma unroll
             for (int i = 0; i < A_DMA; i++) {
@@ -440,13 +414,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         if (g.ablate == 1 && kt >= 2) return;           // timing ablation: no steady-state DMA
 #endif
         char* stage = smem + (kt & 1) * STAGE;
-        if constexpr (X3) {                         // piece i: operand = i >> 2, row group = (i >> 1) & 1, array (hi | lo) = i & 1
-            const int op = i >> 2, rg = (i >> 1) & 1, lo = i & 1;
-            const char* base = op ? (lo ? Blo : Bb) : (lo ? Alo : Ab);
-            const int d = op * 32768 + lo * 16384 + (wave * 2 + rg) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)(soff[op * 2 + rg] + (uint32_t)kt * 64)),
-                                             (__attribute__((address_space(3))) void*)(stage + d), 16, 0, 0);
-        } else {
+        {
             const uint32_t koff = (uint32_t)kt * ROWB;
             const char* base = i < A_DMA ? Ab : Bb;
             const int d = i < A_DMA ? (wave * A_DMA + i) * 8 * ROWB : BM * ROWB + (wave * B_DMA + (i - A_DMA)) * 8 * ROWB;
@@ -463,9 +431,9 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
 
     // fragment addresses: row = tile row + l32, logical chunk = 2 ks + hi; the swizzle term depends on
     // l32 only (tile row offsets are multiples of 32), so one XOR per k16 sub-step serves all tiles
-    const int sw = X3 ? (l32 >> 2) & 3 : (l32 >> 1) & 7;
-    const int a_row_off = X3 ? (wm * 128 + l32) * 64 : (wm * 128 + l32) * ROWB;
-    const int b_row_off = X3 ? 32768 + (wn * 64 + l32) * 64 : BM * ROWB + (wn * 64 + l32) * ROWB;
+    const int sw = (l32 >> 1) & 7;
+    const int a_row_off = (wm * 128 + l32) * ROWB;
+    const int b_row_off = BM * ROWB + (wn * 64 + l32) * ROWB;
     float* const stg = reinterpret_cast<float*>(smem + 65536) + wave * (32 * SROW);
 
     int tile = blockIdx.x;
@@ -519,119 +487,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         if (drain32) PNP_WAIT_VM(32);
         else PNP_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();               // slab 0 complete; staging area (slot 1) no longer read
-        if constexpr (X3) {
-            // Split-bf16 main loop.  Slab = 32 k of (A_hi | A_lo) and (B_hi | B_lo); two k16 sub-steps of 24 MFMAs per wave.
-            // The A fragments (hi, lo) of row tile j are dead after its six MFMAs and are refilled in place with the next
-            // sub-step's; only the B fragments are double-buffered (192 of the 256 registers: 128 accumulators + 64 fragment).
-            // Hand-over as in the bf16 loop: the barrier sits in front of a slab's LAST sub-step, whose operands are in
-            // registers, so its MFMAs cover the barrier, the DMA issue of slab t+2 and the first reads of slab t+1.
-            bf16x8 ah[TM - 1], al[TM - 1], xh0, xl0, xh1, xl1, bh0[TN], bl0[TN], bh1[TN], bl1[TN];
-            auto rd_a = [&](bf16x8& h, bf16x8& l, int kt, int ks, int j) {
-                const char* st = smem + (kt & 1) * STAGE + a_row_off + j * 2048 + (((ks * 2 + hi) ^ sw) << 4);
-                h = *reinterpret_cast<const bf16x8*>(st);
-                l = *reinterpret_cast<const bf16x8*>(st + 16384);
-            };
-            auto rd_b = [&](bf16x8* bh, bf16x8* bl, int kt, int ks, int i) {
-                const char* st = smem + (kt & 1) * STAGE + b_row_off + i * 2048 + (((ks * 2 + hi) ^ sw) << 4);
-                bh[i] = *reinterpret_cast<const bf16x8*>(st);
-                bl[i] = *reinterpret_cast<const bf16x8*>(st + 16384);
-            };
-            // one sub-step on (ah, al, [xh, xl], bh, bl), small terms first; REFILL: the next sub-step's fragments from
-            // (kt_n, ks_n) -- row tiles 0..2 in place behind their MFMAs, the last row tile into the other of its two register
-            // sets (xhn, xln) right behind the first tile's MFMAs (so no read is issued behind the last MFMAs of a sub-step
-            // and the wait in front of the barrier finds every read long complete), B into (bhn, bln); DMA: the 8 pieces of
-            // slab kt_d, two behind each row tile's MFMAs
-            auto sub = [&](const bf16x8& xh, const bf16x8& xl, bf16x8& xhn, bf16x8& xln, const bf16x8* bh, const bf16x8* bl, bf16x8* bhn,
-                           bf16x8* bln, int kt_n, int ks_n, auto refill, auto dma, int kt_d) {
-#pragma unroll
-                for (int j = 0; j < TM; j++) {
-                    const bf16x8& fh = j < TM - 1 ? ah[j < TM - 1 ? j : 0] : xh;
-                    const bf16x8& fl = j < TM - 1 ? al[j < TM - 1 ? j : 0] : xl;
-#ifdef PNP_X3_MFMA16_TIMING
-                    // TIMING-ONLY experiment (results are garbage): the same operands, registers and FLOPs per instruction
-                    // slot as two v_mfma_f32_16x16x32_bf16 on 4-register slices of the accumulator
-                    auto mm16 = [&](f32x16& c, const bf16x8& b, const bf16x8& a, int h) {
-                        f32x4 c0 = {c[8 * h + 0], c[8 * h + 1], c[8 * h + 2], c[8 * h + 3]}, c1 = {c[8 * h + 4], c[8 * h + 5], c[8 * h + 6], c[8 * h + 7]};
-                        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c0, 0, 0, 0);
-                        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            c[8 * h + e] = c0[e];
-                            c[8 * h + 4 + e] = c1[e];
-                        }
-                    };
-#pragma unroll
-                    for (int i = 0; i < TN; i++) mm16(acc[i][j], bl[i], fh, 0);
-#pragma unroll
-                    for (int i = 0; i < TN; i++) mm16(acc[i][j], bh[i], fl, 1);
-#pragma unroll
-                    for (int i = 0; i < TN; i++) mm16(acc[i][j], bh[i], fh, 0);
-#else
-#pragma unroll
-                    for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[i], fh, acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], fl, acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < TN; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[i], fh, acc[i][j], 0, 0, 0);
-#endif
-                    if constexpr (decltype(dma)::value) {
-                        issue_one(kt_d, 2 * j);
-                        issue_one(kt_d, 2 * j + 1);
-                    }
-                    if constexpr (decltype(refill)::value) {
-                        if (j < TM - 1) rd_a(ah[j < TM - 1 ? j : 0], al[j < TM - 1 ? j : 0], kt_n, ks_n, j);
-                        if (j == 0) rd_a(xhn, xln, kt_n, ks_n, TM - 1);
-                        if (j == 1) {
-                            rd_b(bhn, bln, kt_n, ks_n, 0);
-                            rd_b(bhn, bln, kt_n, ks_n, 1);
-                        }
-                    }
-                    if constexpr (decltype(dma)::value) {           // one piece behind every third MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                    } else {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-                    }
-                    if constexpr (decltype(refill)::value) {
-                        if (j == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                        else if (j == 1) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-                        else if (j == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                    }
-                }
-            };
-            constexpr std::true_type yes{};
-            constexpr std::false_type no{};
-#pragma unroll
-            for (int i = 0; i < NDMA; i++) issue_one(1, i);     // nk >= 2
-#pragma unroll
-            for (int j = 0; j < TM - 1; j++) rd_a(ah[j], al[j], 0, 0, j);
-            rd_a(xh0, xl0, 0, 0, TM - 1);
-#pragma unroll
-            for (int i = 0; i < TN; i++) rd_b(bh0, bl0, 0, 0, i);
-            // sub-step 0 of a slab works on (x0, b0) and refills (x1, b1) from the same slab's second half; sub-step 1 works on
-            // (x1, b1) and refills (x0, b0) from the next slab.  The compiler's counted lgkmcnt waits cover the register
-            // dependencies; only the wait in front of the barrier is explicit (the slot is about to be overwritten)
-            int kt = 0;
-            for (; kt + 2 < nk; kt++) {                 // steady state: slab kt+2 exists
-                sub(xh0, xl0, xh1, xl1, bh0, bl0, bh1, bl1, kt, 1, yes, no, 0);
-                __builtin_amdgcn_sched_barrier(0);      // keep the sub-step's last MFMAs in front of the wait
-                PNP_WAIT_VM_LGKM(0);                    // own reads of slab kt complete, own pieces of slab kt+1 landed
-                __builtin_amdgcn_s_barrier();           // slab kt+1 complete; nobody reads slab kt's slot any more
-                __builtin_amdgcn_sched_barrier(0);
-                sub(xh1, xl1, xh0, xl0, bh1, bl1, bh0, bl0, kt + 1, 0, yes, yes, kt + 2);
-            }
-            sub(xh0, xl0, xh1, xl1, bh0, bl0, bh1, bl1, kt, 1, yes, no, 0);   // second-to-last slab: nothing left to fetch
-            __builtin_amdgcn_sched_barrier(0);
-            PNP_WAIT_VM_LGKM(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            sub(xh1, xl1, xh0, xl0, bh1, bl1, bh0, bl0, kt + 1, 0, yes, no, 0);
-            kt++;
-            sub(xh0, xl0, xh1, xl1, bh0, bl0, bh1, bl1, kt, 1, yes, no, 0);   // last slab
-            sub(xh1, xl1, xh0, xl0, bh1, bl1, bh0, bl0, 0, 0, no, no, 0);
-        } else {
+        {
             if (nk > 1) {
     #pragma unroll
                 for (int i = 0; i < NDMA; i++) issue_one(1, i);
@@ -699,7 +555,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         f32x4 rv[8];
         f32x4 bacc[TN][4];                          // bf16 epilogues: bias in the accumulator layout
-        if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16 || EPI == WIDE_GELU_SPLIT || EPI == WIDE_SPLIT) {
+        if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16) {
 #pragma unroll
             for (int i = 0; i < TN; i++)
 #pragma unroll
@@ -707,9 +563,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                     const int nn = en0 + wn * 64 + i * 32 + gq * 8 + hi * 4;
                     bacc[i][gq] = (g.bias && nn < g.Nvalid) ? *reinterpret_cast<const f32x4*>(g.bias + nn) : bv;
                 }
-        }
-        if constexpr (EPI == WIDE_BIAS_F32) {
-            if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
         }
         if constexpr (EPI == WIDE_RESID_F32) {
             if (g.bias && nv) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
@@ -723,7 +576,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
             }
         }
         float brow[TM] = {0.f, 0.f, 0.f, 0.f};        // TOKCOLS: bias of this lane's row in each 32-row tile
-        if constexpr (EPI == WIDE_TOKCOLS_BF16 || EPI == WIDE_TOKCOLS_F32) {
+        if constexpr (EPI == WIDE_TOKCOLS_BF16) {
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const int m = em0 + wm * 128 + j * 32 + l32;
@@ -786,102 +639,6 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
                     }
                 }
             }
-        } else if constexpr (EPI == WIDE_TOKCOLS_F32) {
-            // as above with an fp32 output (the split-bf16 mode feeds fp32 attention kernels): 32-row quarters staged as
-            // fp32 with the row bias added in the accumulator layout; a lane owns a pair of token columns (8-byte stores,
-            // 256 contiguous bytes per row) when col_div is even, else single tokens
-            const bool pairs = (g.col_div & 1) == 0;
-            const int tl0 = pairs ? 2 * l32 : lane;
-            const int tok = en0 + wn * 64 + tl0;
-            size_t ocol = tok;
-            if (g.col_div > 0) {
-                const int b = tok / g.col_div;
-                const int tl = tok - b * g.col_div;
-                ocol = (size_t)b * g.col_pad + tl;
-            }
-            float* const ocolp = g.out_f32 + ocol;
-            const bool tv = tok < g.Nvalid;
-#pragma unroll
-            for (int qd = 0; qd < 4; qd++) {
-                const int mbase = em0 + wm * 128 + qd * 32;
-#pragma unroll
-                for (int i = 0; i < TN; i++)
-#pragma unroll
-                    for (int gq = 0; gq < 4; gq++) {
-                        const f32x16& a = acc[i][qd];
-                        const float br = brow[qd];
-                        const f32x4 v = {a[gq * 4] + br, a[gq * 4 + 1] + br, a[gq * 4 + 2] + br, a[gq * 4 + 3] + br};
-                        *reinterpret_cast<f32x4*>(stg + l32 * SROW + i * 32 + gq * 8 + hi * 4) = v;
-                    }
-                if (pairs) {
-                    f32x2 sv[16];
-#pragma unroll
-                    for (int it = 0; it < 16; it++) sv[it] = *reinterpret_cast<const f32x2*>(stg + (it * 2 + hi) * SROW + tl0);
-#pragma unroll
-                    for (int it = 0; it < 16; it++) {
-                        const int m = mbase + it * 2 + hi;
-                        if (tv && m < g.M) *reinterpret_cast<f32x2*>(ocolp + (size_t)m * g.ldo) = sv[it];
-                    }
-                } else {
-#pragma unroll 8
-                    for (int row = 0; row < 32; row++) {
-                        const float v = stg[row * SROW + lane];
-                        if (tv && mbase + row < g.M) ocolp[(size_t)(mbase + row) * g.ldo] = v;
-                    }
-                }
-            }
-        } else if constexpr (EPI == WIDE_GELU_SPLIT || EPI == WIDE_SPLIT) {
-            // bias + erf-form GELU (|erf error| <= 1.5e-7) in the accumulator layout, written back into the accumulators;
-            // then two passes over the bf16 staging of the plain bf16 epilogue: hi = bf16(v) -> out_t, lo = bf16(v - hi)
-            // -> out_lo (the pair carries 16 significant bits of v)
-            constexpr int HROW = 68;
-            bf16* const stgh = reinterpret_cast<bf16*>(smem + 65536) + wave * (64 * HROW);
-            const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
-#pragma unroll
-            for (int j = 0; j < TM; j++)
-#pragma unroll
-                for (int i = 0; i < TN; i++)
-#pragma unroll
-                    for (int gq = 0; gq < 4; gq++)
-#pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            pnp_f32x2 v = {acc[i][j][gq * 4 + e] + bacc[i][gq][e], acc[i][j][gq * 4 + e + 1] + bacc[i][gq][e + 1]};
-                            if constexpr (EPI == WIDE_GELU_SPLIT) v = gelu_erf_fast2(v);
-                            acc[i][j][gq * 4 + e] = v[0];
-                            acc[i][j][gq * 4 + e + 1] = v[1];
-                        }
-#pragma unroll
-            for (int part = 0; part < 2; part++) {
-                bf16* const obase = reinterpret_cast<bf16*>(part ? g.out_lo : g.out_t) + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo_t + n;
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-#pragma unroll
-                    for (int jj = 0; jj < 2; jj++)
-#pragma unroll
-                        for (int i = 0; i < TN; i++)
-#pragma unroll
-                            for (int gq = 0; gq < 4; gq++) {
-                                const f32x16& a = acc[i][half * 2 + jj];
-                                bf16x4 pk;
-#pragma unroll
-                                for (int e = 0; e < 4; e++) {
-                                    const float v = a[gq * 4 + e];
-                                    const bf16 h = (bf16)v;
-                                    pk[e] = part ? (bf16)(v - (float)h) : h;
-                                }
-                                *reinterpret_cast<bf16x4*>(stgh + (jj * 32 + l32) * HROW + i * 32 + gq * 8 + hi * 4) = pk;
-                            }
-                    bf16x4 sv[16];
-#pragma unroll
-                    for (int it = 0; it < 16; it++)
-                        sv[it] = *reinterpret_cast<const bf16x4*>(stgh + (it * 4 + (lane >> 4)) * HROW + (lane & 15) * 4);
-#pragma unroll
-                    for (int it = 0; it < 16; it++) {
-                        const int m = em0 + wm * 128 + half * 64 + it * 4 + (lane >> 4);
-                        if (full || (m < g.M && nv)) *reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t) = sv[it];
-                    }
-                }
-            }
         } else if constexpr (EPI == WIDE_BF16 || EPI == WIDE_GELU_BF16) {
             // bias (+GELU) and the bf16 rounding happen in the accumulator layout; the tile is staged as bf16
             // (half the LDS bytes: LDS stores run at ~80 B/clk/CU) in two 64-row halves, 136-byte rows so the
@@ -928,7 +685,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
             // fp32 residual epilogue, 32-row quarters staged as fp32.  The residual rows of quarter q+1 are
             // requested before the stores of quarter q (two register sets), so each wait has a whole quarter
             // of work in front of it and never sits behind a store.
-            constexpr bool kResid = EPI == WIDE_RESID_F32;      // WIDE_BIAS_F32: same path without the residual rows
+            constexpr bool kResid = EPI == WIDE_RESID_F32;
             const bool full = (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
             const float* const rbase = kResid ? g.resid + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldr + n : nullptr;
             float* const obase = g.out_f32 + (size_t)(em0 + wm * 128 + (lane >> 4)) * g.ldo + n;
@@ -969,7 +726,7 @@ __global__ __launch_bounds__(512) void gemm_nt_wide_kernel(const GemmArgs g) {
         if (next >= ntiles) break;
         tile = next;
         // every lane of a full tile executes all of the epilogue's stores (32 per wave, 64 for the split pair)
-        drain32 = (EPI != WIDE_TOKCOLS_BF16 && EPI != WIDE_TOKCOLS_F32) && (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+        drain32 = EPI != WIDE_TOKCOLS_BF16 && (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
     }
     if (g.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1001,7 +758,7 @@ static int wide_epilogue_kind(const GemmArgs& g) {
     return -1;
 }
 
-template <int EPI, bool X3>
+template <int EPI>
 static int launch_wide(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
     static const int n_cu = [] {
@@ -1012,7 +769,7 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
     }();
     if (!n_cu) return PNP_ERR_HIP;
     // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI, X3>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideSmem);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideSmem);
     if (attr != hipSuccess) return PNP_ERR_HIP;
     const int ntiles = nbm * nbn;
     int cap = n_cu;
@@ -1020,7 +777,7 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
     if (getenv("PNP_GEMM_GRID")) cap = atoi(getenv("PNP_GEMM_GRID"));
 #endif
     const int grid = ntiles > cap ? cap : ntiles;        // one workgroup per CU (LDS-limited) walks the tiles
-    hipLaunchKernelGGL((gemm_nt_wide_kernel<EPI, X3>), dim3(grid), dim3(512), kWideSmem, s, g);
+    hipLaunchKernelGGL((gemm_nt_wide_kernel<EPI>), dim3(grid), dim3(512), kWideSmem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
@@ -1030,7 +787,7 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
 // exact-fp32 form of these launches is MFMA-bound at ~40 us each (1188 launches per bench step); here the activation tile is
 // split into (hi, lo) bf16 ONCE by the threads that stage it (global -> registers -> two 16-byte LDS stores per 8 values),
 // the weight tile arrives by LDS-DMA already split, and each fragment pair issues three v_mfma_f32_16x16x32_bf16
-// (a_hi.b_lo, a_lo.b_hi, a_hi.b_hi: fp32-class product, see the wide kernel's X3 note).
+// (a_hi.b_lo, a_lo.b_hi, a_hi.b_hi: fp32-class product, see gemm_x3.hip).
 // Tile 64 x 64, 4 waves of 32 x 32, 32-deep k-slabs, 4-slot ring (three slabs in flight): slot = A_hi | A_lo | B_hi | B_lo, each 64 rows x 64 bytes,
 // 16-byte chunks swizzled chunk ^= (-(row >> 2)) & 3 (the 16 lanes a ds_read_b128 services together -- 4 rows of one q
 // and 8 rows of the next -- then hit 16 different slots).  Epilogue: the generic store_frag (bias, residual, GELU + stash,
@@ -1449,7 +1206,7 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     //   bf16 ViT-block epilogues (bias -> bf16 | bias+GELU -> bf16 | bias+residual -> f32), >= 128 tiles:
     //       gemm_nt_wide_kernel, 256 x 256, 32x32x16 MFMA; main loop ~2350 clk per 64-deep slab against
     //       2048 MFMA clk, epilogue staged through LDS (full-line stores)
-    //   split-bf16 operands       : always the wide kernel (its X3 form)
+    //   split-bf16 operands       : always gemm_nt_x3_kernel (gemm_x3.hip)
     //   other bf16 with K >= 2048 : generic 256 x 256 (16x16x32 MFMA, simple ring)
     //   otherwise                 : generic 128 x 128, two workgroups per CU
     int r;
@@ -1459,21 +1216,12 @@ int gemm_nt(int dtype_bf16, GemmArgs g, hipStream_t s) {
     if (x3) {
         if (wide < 0) return PNP_ERR_ARG;
         g.N = (g.Nvalid + 255) / 256 * 256;
-#ifdef PNP_DEV
-        if (!dev_env("PNP_X3_OLD", 0)) r = launch_x3_wide(wide, g, s); else
-#else
         r = launch_x3_wide(wide, g, s);
-        if (false)
-#endif
-        r = wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32, true>(g, s)
-            : wide == WIDE_BIAS_F32 ? launch_wide<WIDE_BIAS_F32, true>(g, s)
-            : wide == WIDE_GELU_SPLIT ? launch_wide<WIDE_GELU_SPLIT, true>(g, s)
-            : wide == WIDE_SPLIT ? launch_wide<WIDE_SPLIT, true>(g, s) : launch_wide<WIDE_TOKCOLS_F32, true>(g, s);
     } else if (wide >= 0 && (variant == 4 || (variant == 0 && tiles256 >= 128))) {
         g.N = (g.Nvalid + 255) / 256 * 256;
-        r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16, false>(g, s)
-            : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16, false>(g, s)
-            : wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32, false>(g, s) : launch_wide<WIDE_TOKCOLS_BF16, false>(g, s);
+        r = wide == WIDE_BF16 ? launch_wide<WIDE_BF16>(g, s)
+            : wide == WIDE_GELU_BF16 ? launch_wide<WIDE_GELU_BF16>(g, s)
+            : wide == WIDE_RESID_F32 ? launch_wide<WIDE_RESID_F32>(g, s) : launch_wide<WIDE_TOKCOLS_BF16>(g, s);
     } else if (variant == 1) {
         r = dtype_bf16 ? launch_big<bf16, 256, 128, 64, 64, 3>(g, s) : launch_big<float, 256, 128, 64, 64, 3>(g, s);
     } else if (dtype_bf16 && (variant == 2 || (variant == 0 && big_k))) {

@@ -23,10 +23,10 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_
 echo "pmc mfma rc=$?"
 B1="--steps 1 --warmup 1 --pipelines 1 --no-cpu-baseline --no-other-modes --no-other-configs --no-noise12"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "gemm_nt_wide|crf_" -d $OUT/${TAG}_pmc_$c -o pmc --output-format csv \
+  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "gemm_nt_wide|gemm_nt_x3|crf_" -d $OUT/${TAG}_pmc_$c -o pmc --output-format csv \
     -- python3 $R/bench.py $B1 > $OUT/${TAG}_pmc_$c.log 2>&1
   echo "pmc $c rc=$?"
-  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "gemm_nt_wide" -d $OUT/${TAG}_pmc_bf16_$c -o pmc --output-format csv \
+  rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "gemm_nt_wide|gemm_nt_x3" -d $OUT/${TAG}_pmc_bf16_$c -o pmc --output-format csv \
     -- python3 $R/bench.py --dtype bf16 $B1 > $OUT/${TAG}_pmc_bf16_$c.log 2>&1
   echo "pmc bf16 $c rc=$?"
 done

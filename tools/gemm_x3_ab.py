@@ -1,10 +1,11 @@
 """A/B of split-bf16 wide-GEMM builds IN ONE PROCESS on one GPU (boxes differ by several percent in clock, so variants are
-only comparable inside a run): each variant is a library file next to the product one plus optional environment knobs of the
-DEV build (PNP_X3_OLD=1: the 32x32x16 kernel of round 3), timed interleaved over several rounds, best-of reported.
+only comparable inside a run): each variant is a library file next to the product one (e.g. built from another commit or with
+`-DPNP_X3_ABLATE=n`, the timing-only ablations of csrc/gemm_x3.hip: garbage results) plus optional environment knobs of a DEV
+build, timed interleaved over several rounds, best-of reported.  This is how round 4 compared the 16x16x32 kernel with the
+32x32x16 kernel of round 3 (numbers in DESIGN.md section 5).
 
     python tools/gemm_x3_ab.py [shape ...] name=lib[:ENV=V,...] ...
-    e.g.  new=libpnp_hip.so old=libpnp_hip_dev.so:PNP_X3_OLD=1 nodma=libpnp_hip_abl1.so
-Timing-only builds (`-DPNP_X3_ABLATE=n`, garbage results): see csrc/gemm_x3.hip."""
+    e.g.  new=libpnp_hip.so other=libpnp_hip_other.so nodma=libpnp_hip_abl1.so"""
 import ctypes as C
 import os
 import sys
@@ -15,9 +16,9 @@ LIBDIR = os.path.join(ROOT, "pnp-ovss_amd", "pnp_ovss")
 import torch
 
 args = sys.argv[1:]
-specs = [a for a in args if "=" in a.split(":")[0]] or ["new=libpnp_hip.so", "old=libpnp_hip_dev.so:PNP_X3_OLD=1"]
+specs = [a for a in args if "=" in a.split(":")[0]] or ["product=libpnp_hip.so", "dev=libpnp_hip_dev.so"]
 only = [a for a in args if "=" not in a]
-KNOBS = ("PNP_X3_OLD", "PNP_GEMM_ABLATE", "PNP_GEMM_GRID")
+KNOBS = ("PNP_GEMM_GM", "PNP_GEMM_GRID")
 vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
 variants = []
 for sp in specs:

@@ -1,7 +1,7 @@
 """Turn the raw rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/<tag>_*) into the small committed summaries
 under profiles/: kernel-stats table, MFMA-busy table, HBM traffic per launch (FETCH_SIZE doubled for 16-byte-per-lane
 reads on gfx950, as MI355X_MICROARCH.md prescribes) for the GEMM and the CRF kernels.
-usage: python tools/summarize_profiles.py r03"""
+usage: python tools/summarize_profiles.py r04"""
 import collections
 import csv
 import json
@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -80,7 +80,7 @@ def main():
     json.dump(out, open(os.path.join(P, f"{TAG}_mfma_busy.json"), "w"), indent=1)
     tr = traffic("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", " -- headline mode bf16x3")
     json.dump(tr, open(os.path.join(P, f"{TAG}_hbm_traffic.json"), "w"), indent=1)
-    g = {k: v for k, v in tr["kernels"].items() if "gemm_nt_wide" in k}
+    g = {k: v for k, v in tr["kernels"].items() if "gemm_nt_wide" in k or "gemm_nt_x3" in k}
     json.dump({"note": tr["note"], "kernels": g}, open(os.path.join(P, f"{TAG}_gemm_traffic_bf16x3.json"), "w"), indent=1)
     if os.path.exists(os.path.join(G, f"{TAG}_pmc_bf16_FETCH_SIZE")):
         tb = traffic("pmc_bf16_FETCH_SIZE", "pmc_bf16_WRITE_SIZE", " -- bf16 throughput mode")
