@@ -348,8 +348,12 @@ def run_rank(a):
             self._inputs = {}
 
         def inputs(self, noise):
+            """noise: +-grey levels of the block images, or "photo": the photograph-like generator (synth.synth_photo_images)."""
             if noise not in self._inputs:
-                rgb, imgs = synth.synth_images(self.B, self.img, seed=1234 + rank, noise=noise)
+                if noise == "photo":
+                    rgb, imgs = synth.synth_photo_images(self.B, self.img, seed=1234 + rank)
+                else:
+                    rgb, imgs = synth.synth_images(self.B, self.img, seed=1234 + rank, noise=noise)
                 self._inputs[noise] = (torch.from_numpy(imgs).to(dev), torch.from_numpy(rgb.reshape(-1)).to(dev))
             return self._inputs[noise]
 
@@ -502,6 +506,8 @@ def run_rank(a):
                                           "all channel groups), bracketed by hipEvents per batch",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "ms_per_step": ms / max(steps, 1), "algorithmic_bytes_per_step": nbytes / max(steps, 1),
+                "byte_model": "per mean-field iteration (2*9 + 2) * K*H*W*4 (splat + slice of 3 + 6 simplex vertices, Q read and written) "
+                              "+ 2 * (2*M_gauss + 3*M_bilateral) * K*4 (the lattice value arrays read and written once per pass of two blur axes)",
                 "bilateral_lattice_points_per_pixel": ppp}
 
     def traffic_for(dtype):
@@ -605,6 +611,14 @@ def run_rank(a):
                 dt2p, _ = wl.timed_run_pipelined(P, NOISE_HARD, a.steps, 1)
                 out["noise12"].update({"value": wl.B * a.steps / dt2p, "ms_per_step": 1e3 * dt2p / a.steps, "steps": a.steps,
                                        "batches_in_flight": P, "one_batch_at_a_time": {"value": wl.B * n2 / dt2, "ms_per_step": 1e3 * dt2 / n2}})
+        if single and not a.no_noise12:
+            # third operating point: photograph-like images (soft-edged regions, illumination gradients, texture, sensor
+            # noise of 3 grey levels) -- fewer distinct colours than the random 8x8 blocks, so FEWER bilateral lattice points
+            n3 = max(1, min(a.steps, 2))
+            dt3, _, _, crf3, ppp3 = wl.timed_run("photo", n3, 1)
+            out["photo"] = {"value": wl.B * n3 / dt3, "unit": "images/sec", "ms_per_step": 1e3 * dt3 / n3, "steps": n3,
+                            "images": "synth.synth_photo_images(sigma=3)", "batches_in_flight": 1, "crf": roofline_crf(crf3, n3, ppp3)}
+            out["crf"]["photo_like_operating_point"] = out["photo"]["crf"]
         labels_head = state["ln"].clone()
         wl.close()
         torch.cuda.empty_cache()

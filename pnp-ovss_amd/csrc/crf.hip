@@ -888,7 +888,7 @@ size_t crf_sort_temp_bytes(size_t max_entries, int max_images) {
 int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
                       int B, size_t ent_total, int max_pixels,
                       uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
-                      void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, hipStream_t s) {
+                      void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, int* h_points, hipStream_t s) {
     const int nb = (max_pixels + 255) / 256 < 512 ? (max_pixels + 255) / 256 : 512;
     if (D == 2)
         hipLaunchKernelGGL((lattice_embed_kernel<2>), dim3(nb, B), dim3(256), 0, s, d_imgs, d_rgb, sxy, srgb, L.bary, keys_a, vals_a, d_range_err);
@@ -923,6 +923,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     if (hipStreamSynchronize(s) != hipSuccess) return PNP_ERR_HIP;
     if (err && h_range_err) *h_range_err = 1;
     if (M <= 0 || (size_t)M > ent_total) return PNP_ERR_STATE;
+    if (h_points) *h_points = M;                          // lattice points of the batch (bench.py: lattice term of the byte model)
     uint64_t* fkey = keys_a;
     uint64_t* skey = keys_b;
     uint32_t* fid = vals_a;                               // (the first sort's input: free by now)

@@ -123,6 +123,7 @@ struct pnp_engine {
         int *n1k = nullptr, *n2k = nullptr;
         int *head = nullptr, *incl = nullptr, *range_err = nullptr;
         int range_err_host = 0;                // key-range flag of the lattices built by the last prepare
+        int lat_points[2] = {0, 0};            // lattice points of the prepared batch (Gaussian, bilateral)
         std::vector<size_t> h_label_off;       // host staging of the per-batch tables (see pnp_post_prepare)
         std::vector<int32_t> h_wt_off;
         std::vector<double> h_wts;
@@ -1255,7 +1256,7 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
             const int D1 = t == 0 ? 3 : 6;
             KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
                                       p.maxHW, p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
-                                      p.n1k, p.n2k, p.sort_tmp, p.sort_tmp_bytes, p.range_err, &p.range_err_host, s));
+                                      p.n1k, p.n2k, p.sort_tmp, p.sort_tmp_bytes, p.range_err, &p.range_err_host, &p.lat_points[t], s));
             KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.maxHW, (size_t)pix * D1, p.va, p.vb, p.norm[t], s));
             synced = true;
         }
@@ -1332,11 +1333,21 @@ static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t 
         pf.used++;
         pf.launches++;
         // per mean-field iteration splat + slice of (3 + 6) simplex vertices per pixel and channel, each
-        // a 4-byte read or write, plus Q read and written once: (2 * 9 + 2) * K * H * W * 4 bytes
+        // a 4-byte read or write, plus Q read and written once: (2 * 9 + 2) * K * H * W * 4 bytes.  Round 4 adds the term that
+        // grows with the lattice, not with the pixels: the axis blurs read and write the value array of every lattice point
+        // (M_g + M_b points of K floats) once per PASS of two axes -- 2 passes for the Gaussian lattice (d + 1 = 3 axes), 3 for
+        // the bilateral one (6 axes); the published algorithm makes d + 1 -- so the fraction means the same at 0.9 and at 3.6
+        // lattice points per pixel
         const auto& p = e->post;
         const int groups = desc == p.d_desc_pair ? 2 : 1;
-        for (int i = 0; i < p.B; i++)
-            pf.work += (double)iters * 20.0 * 4.0 * groups * p.desc[i].K * (double)p.desc[i].H * p.desc[i].W;
+        double kpix = 0, pix = 0;
+        for (int i = 0; i < p.B; i++) {
+            kpix += (double)p.desc[i].K * p.desc[i].H * p.desc[i].W;
+            pix += (double)p.desc[i].H * p.desc[i].W;
+        }
+        const double kavg = pix > 0 ? kpix / pix : 0;
+        pf.work += (double)iters * 20.0 * 4.0 * groups * kpix;
+        pf.work += (double)iters * 2.0 * 4.0 * groups * kavg * (2.0 * p.lat_points[0] + 3.0 * p.lat_points[1]);
     }
     return r;
 }

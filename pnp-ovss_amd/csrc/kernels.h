@@ -141,7 +141,7 @@ size_t crf_sort_temp_bytes(size_t max_entries, int max_images);
 int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
                       int B, size_t ent_total, int max_pixels,
                       uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
-                      void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, hipStream_t s);
+                      void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, int* h_points, hipStream_t s);
 int crf_lattice_norm(const CrfLattice& L, const PostDesc* d_imgs, int B, int max_pixels, size_t ent_total, float* va, float* vb,
                      float* norm_out, hipStream_t s);
 int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, const float* Q,

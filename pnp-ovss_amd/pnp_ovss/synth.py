@@ -137,6 +137,41 @@ def synth_images(batch: int, size: int, seed: int = 1234, block: int = 8, noise:
     return rgb, np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32)
 
 
+def synth_photo_images(batch: int, size: int, seed: int = 1234, sigma: float = 3.0):
+    """Photograph-like seeded RGB images (the third DenseCRF operating point of bench.py): a few large regions with soft
+    edges (objects), smooth illumination gradients, band-limited texture of region-dependent strength and per-pixel sensor
+    noise of `sigma` grey levels -- what decides how many bilateral lattice points (cells of 50 px x 5 grey levels per
+    channel) an image occupies.  The block images of synth_images() are the two ends: flat 8 x 8 blocks + noise 4 -> 0.9
+    points per pixel, + noise 12 -> 3.6; this generator lands in between (bench.py reports the measured density).
+    Same return convention as synth_images()."""
+    g = np.random.default_rng([seed, 23])
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    out = np.empty((batch, size, size, 3), dtype=np.float32)
+    for b in range(batch):
+        # 5 soft-edged regions (Voronoi cells of random sites, blended over ~6 px), each with its own colour and texture gain
+        sites = g.uniform(0, size, size=(5, 2)).astype(np.float32)
+        d2 = (yy[None] - sites[:, 0, None, None]) ** 2 + (xx[None] - sites[:, 1, None, None]) ** 2
+        w = np.exp(-(np.sqrt(d2) - np.sqrt(d2.min(axis=0, keepdims=True))) / 6.0)
+        w /= w.sum(axis=0, keepdims=True)
+        colour = g.uniform(40, 215, size=(5, 3)).astype(np.float32)
+        gain = g.uniform(0.0, 14.0, size=5).astype(np.float32)
+        img = np.einsum("rhw,rc->hwc", w, colour)
+        # illumination: two low-frequency gradients shared by the channels
+        illum = 18 * np.sin(xx / g.uniform(60, 140) + g.uniform(0, 6.28)) + 14 * np.cos(yy / g.uniform(60, 140) + g.uniform(0, 6.28))
+        # texture: sum of 6 mid-frequency waves, scaled per region
+        tex = np.zeros((size, size), np.float32)
+        for _ in range(6):
+            fx, fy = g.uniform(0.08, 0.5, size=2)
+            tex += np.sin(fx * xx + fy * yy + g.uniform(0, 6.28)).astype(np.float32)
+        tex *= np.einsum("rhw,r->hw", w, gain) / 3.0
+        img = img + (illum + tex)[..., None] + g.normal(0, sigma, size=(size, size, 3)).astype(np.float32)
+        out[b] = img
+    rgb = np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    x = rgb.astype(np.float32) / np.float32(255.0)
+    x = (x - CLIP_MEAN) / CLIP_STD
+    return rgb, np.ascontiguousarray(x.transpose(0, 3, 1, 2)).astype(np.float32)
+
+
 def synth_tokens(cfg: ModelCfg, n_classes_per_image, seed: int = 1234, max_length: int = 500):
     """Synthetic token ids `[CLS] a picture of t1..tC [SEP]` padded to `max_length`
     (the caller's `padding="max_length", max_length=500` tokenisation at

@@ -2,7 +2,7 @@
 bench-shaped batch, without the model: `reps` calls of post_prepare + postprocess_pair, wall time per call and the
 live mean-field time.  Run under `rocprofv3 --kernel-trace --stats` for the per-kernel split (tools/crf_pair_probe.sh).
 
-  python3 tools/crf_pair_probe.py [reps=3] [noise=4] [K=21] [chunk=0]
+  python3 tools/crf_pair_probe.py [reps=3] [noise=4 | photo] [K=21] [chunk=0]
 """
 import json
 import os
@@ -23,7 +23,7 @@ if os.environ.get("PNP_DEV_LIB"):                          # DEV build: the PNP_
 
 B, IMG = 35, 336
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-NOISE = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+NOISE = (sys.argv[2] if sys.argv[2] == "photo" else int(sys.argv[2])) if len(sys.argv) > 2 else 4
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 21        # channels: K - 1 classes + background
 CHUNK = int(sys.argv[4]) if len(sys.argv) > 4 else 0     # images per DenseCRF chunk (0 = the whole batch)
 cfg = C.blip_itm_small(IMG)
@@ -32,7 +32,7 @@ g0 = torch.from_numpy(rng.random((B, K + 3, 21, 21), dtype=np.float32) ** 4).cud
 agg = torch.from_numpy(rng.random((B, K + 3, 21, 21), dtype=np.float32) ** 4).cuda()
 plans = [[([i], 1) for i in range(K - 1)]] * B
 luts = [list(range(K))] * B
-rgb, _ = synth.synth_images(B, IMG, seed=1234, noise=NOISE)
+rgb, _ = synth.synth_photo_images(B, IMG, seed=1234) if NOISE == "photo" else synth.synth_images(B, IMG, seed=1234, noise=NOISE)
 d_rgb = torch.from_numpy(rgb.reshape(-1)).cuda()
 e = Engine(cfg, max_batch=B, max_text_len=max(32, K + 8), stash_layer=1, bf16=True)
 e.post_reserve(B, B * IMG * IMG, IMG * IMG, K, CHUNK)
