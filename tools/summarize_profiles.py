@@ -22,7 +22,7 @@ def kernel_stats(sub, out):
     rows = list(csv.DictReader(open(os.path.join(G, f"{TAG}_{sub}", "prof_kernel_stats.csv"))))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     lines = [f"# rocprofv3 --kernel-trace --stats of `python3 bench.py {'--dtype bf16 ' if 'bf16' in sub else ''}--steps 2 --warmup 1 "
-             f"--pipelines 1 --no-cpu-baseline --no-other-modes --no-other-configs --no-noise12` "
+             f"--pipelines 1 --no-cpu-baseline --no-other-modes --no-other-configs --no-noise12 --no-fixture-check` "
              f"({'bf16 throughput mode' if 'bf16' in sub else 'headline mode bf16x3'}; 3 steps of 35 images in the trace)",
              "# kernel | calls | total ms | avg us | min us | max us | % of GPU time"]
     for r in rows:
