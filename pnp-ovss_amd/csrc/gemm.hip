@@ -784,7 +784,7 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
 // ------------------------------------------------------------------------------------------
 // Text-side GEMM of the split-bf16 mode: C[M,N] = A[M,K] . B[N,K]^T with A = fp32 activations (M = B*L rows, a few hundred
 // to a few thousand) and B = a weight stored as a bf16 (hi | lo) pair.  The fp32 MFMA runs at 1/16 of the bf16 rate, so the
-// exact-fp32 form of these launches is MFMA-bound at ~40 us each (1188 launches per bench step); here the activation tile is
+// exact-fp32 form of these launches is MFMA-bound at ~40 us each (396 launches per 35-image bench step); here the activation tile is
 // split into (hi, lo) bf16 ONCE by the threads that stage it (global -> registers -> two 16-byte LDS stores per 8 values),
 // the weight tile arrives by LDS-DMA already split, and each fragment pair issues three v_mfma_f32_16x16x32_bf16
 // (a_hi.b_lo, a_lo.b_hi, a_hi.b_hi: fp32-class product, see gemm_x3.hip).
