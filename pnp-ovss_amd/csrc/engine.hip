@@ -77,6 +77,7 @@ struct pnp_engine {
     std::vector<Buf> staging;                  // fp32 staging of GEMM weights until finalize
 
     // ---- activations
+    int ldq = 0;               // row stride (elements) of the fused q|k|v buffer
     void *patches = nullptr, *xn = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *h1 = nullptr, *embT = nullptr;
     float *x = nullptr, *emb32 = nullptr;
     void *Knat = nullptr, *Vnat = nullptr, *Kt = nullptr, *Vt = nullptr;
@@ -366,7 +367,11 @@ extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
     KCHK(e, dalloc_t(e, &e->patches, B * e->PP * 768));
     KCHK(e, dalloc(e, &e->x, M * D));
     KCHK(e, dalloc_t(e, &e->xn, M * D));
-    KCHK(e, dalloc_t(e, &e->qk, M * 3 * D));        // bf16 mode: fused q|k|v rows; fp32 mode: q|k rows (v goes to vt)
+    // bf16 / split-bf16 modes: fused q|k|v rows at a stride of 3D + 64 elements; fp32 mode: q|k rows (v goes to vt).
+    // The pad matters: an attention K / V tile is 64 rows x 128 B at the row stride, and at 6144 B (3D bf16, D = 1024) those
+    // rows crowd a few L2 channels -- 151 us per launch against 136-138 us at 6272 ... 6656 B (tools/attn_ld_probe.py)
+    e->ldq = 3 * (int)D + 64;
+    KCHK(e, dalloc_t(e, &e->qk, M * (size_t)e->ldq));
     KCHK(e, dalloc_t(e, &e->vt, D * ldv, true));
     KCHK(e, dalloc_t(e, &e->ctx, M * D));
     KCHK(e, dalloc_t(e, &e->h1, M * D * c.vit_mlp_ratio));
@@ -693,7 +698,7 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
         void* const xn_lo = (char*)e->xn + cap * D * 2;
         void* const ctx_lo = (char*)e->ctx + cap * D * 2;
         void* const h1_lo = (char*)e->h1 + cap * F * 2;
-        void* const qk_lo = (char*)e->qk + cap * 3 * D * 2;
+        void* const qk_lo = (char*)e->qk + cap * e->ldq * 2;
         for (int l = 0; l < e->c.vit_depth; l++) {
             const VitLayerW& w = e->vit[l];
             const char* const qkv_lo = (const char*)w.qkv_w + (size_t)3 * D * D * 2;
@@ -701,10 +706,10 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
             {   // q | k | v in one launch as a (hi, lo) bf16 pair: [M, 3D] each, halves of the qk buffer
                 GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 3 * D, D);
                 g.A_lo = xn_lo; g.B_lo = qkv_lo;
-                g.bias = w.qkv_b; g.out_t = e->qk; g.out_lo = qk_lo; g.ldo_t = 3 * D;
+                g.bias = w.qkv_b; g.out_t = e->qk; g.out_lo = qk_lo; g.ldo_t = e->ldq;
                 KCHK(e, egemm(e, 1, g, s));
             }
-            KCHK(e, vit_attention_x3(e->qk, qk_lo, 3 * D, D, e->ctx, ctx_lo, B, e->c.vit_heads, N, scale, s));
+            KCHK(e, vit_attention_x3(e->qk, qk_lo, e->ldq, D, e->ctx, ctx_lo, B, e->c.vit_heads, N, scale, s));
             {
                 GemmArgs g = G_(e->ctx, D, w.proj_w, D, M, D, D);
                 g.A_lo = ctx_lo; g.B_lo = (const char*)w.proj_w + (size_t)D * D * 2;
@@ -734,9 +739,9 @@ extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8
         KCHK(e, layernorm(bf, e->x, w.n1w, w.n1b, e->c.vit_ln_eps, M, D, nullptr, e->xn, nullptr, nullptr, s));
         if (bf) {   // q | k | v natural in one launch: [M, 3D]; the attention kernel transposes V on its LDS reads
             GemmArgs g = G_(e->xn, D, w.qkv_w, D, M, 3 * D, D);
-            g.bias = w.qkv_b; g.out_t = e->qk; g.ldo_t = 3 * D;
+            g.bias = w.qkv_b; g.out_t = e->qk; g.ldo_t = e->ldq;
             KCHK(e, egemm(e, bf, g, s));
-            KCHK(e, vit_attention(bf, e->qk, 3 * D, D, (const char*)e->qk + (size_t)2 * D * e->esz, 3 * D, e->Npad, e->ctx, B,
+            KCHK(e, vit_attention(bf, e->qk, e->ldq, D, (const char*)e->qk + (size_t)2 * D * e->esz, e->ldq, e->Npad, e->ctx, B,
                                   e->c.vit_heads, N, scale, s));
         } else {
         {   // q | k  natural: [M, 2D]

@@ -17,18 +17,19 @@ if "--dev" in sys.argv:
 if "--lib" in sys.argv:                                     # a named library variant next to the product one (A/B runs)
     hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
 lib = hip.load_library()
+PAD = int(sys.argv[sys.argv.index("--pad") + 1]) if "--pad" in sys.argv else 64   # the engine's q|k|v row stride is 3D + 64
 
 
 def run(B, H, N):
     D = H * 64
     torch.manual_seed(0)
-    qkv = torch.randn(B * N, 3 * D, device="cuda")
+    qkv = torch.randn(B * N, 3 * D + PAD, device="cuda")
     hi = torch.empty(qkv.shape, device="cuda", dtype=torch.bfloat16)
     lo = torch.empty_like(hi)
     assert lib.pnp_op_split(qkv.data_ptr(), hi.data_ptr(), lo.data_ptr(), qkv.numel(), None) == 0
     ch = torch.empty(B * N, D, device="cuda", dtype=torch.bfloat16)
     cl = torch.empty_like(ch)
-    call = lambda: lib.pnp_op_vit_attention_x3(hi.data_ptr(), lo.data_ptr(), 3 * D, D, ch.data_ptr(), cl.data_ptr(), B, H, N, 0.125, None)
+    call = lambda: lib.pnp_op_vit_attention_x3(hi.data_ptr(), lo.data_ptr(), 3 * D + PAD, D, ch.data_ptr(), cl.data_ptr(), B, H, N, 0.125, None)
     for _ in range(3):
         assert call() == 0
     torch.cuda.synchronize()
@@ -38,12 +39,14 @@ def run(B, H, N):
     ref = torch.softmax(q @ k.t() * 0.125, dim=-1) @ v
     got = (ch[:N, :64].float() + cl[:N, :64].float()).double()
     err = float((got - ref).abs().max() / ref.abs().max())
-    n = 50
-    t0 = time.perf_counter()
-    for _ in range(n):
-        call()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n
+    n = 40
+    dt = 1e9
+    for rep in range(4):                                   # the first repetition runs while the clock settles: best of four
+        t0 = time.perf_counter()
+        for _ in range(n):
+            call()
+        torch.cuda.synchronize()
+        dt = min(dt, (time.perf_counter() - t0) / n)
     fl = 4.0 * N * N * 64 * H * B
     print(f"B={B} H={H} N={N}: {dt * 1e6:7.1f} us  algorithmic {fl / dt / 1e12:6.0f} TF  issued {3 * fl / dt / 1e12:6.0f} TF  relerr {err:.1e}", flush=True)
 
@@ -58,14 +61,14 @@ if "--stamps" in sys.argv:
     lib.pnp_dev_attn_stamps.argtypes = [C.c_void_p]
     assert lib.pnp_dev_attn_stamps(buf.data_ptr()) == 0
     torch.manual_seed(0)
-    qkv = torch.randn(B * N, 3 * D, device="cuda")
+    qkv = torch.randn(B * N, 3 * D + PAD, device="cuda")
     hi = torch.empty(qkv.shape, device="cuda", dtype=torch.bfloat16)
     lo = torch.empty_like(hi)
     lib.pnp_op_split(qkv.data_ptr(), hi.data_ptr(), lo.data_ptr(), qkv.numel(), None)
     ch = torch.empty(B * N, D, device="cuda", dtype=torch.bfloat16)
     cl = torch.empty_like(ch)
     for _ in range(3):
-        lib.pnp_op_vit_attention_x3(hi.data_ptr(), lo.data_ptr(), 3 * D, D, ch.data_ptr(), cl.data_ptr(), B, H, N, 0.125, None)
+        lib.pnp_op_vit_attention_x3(hi.data_ptr(), lo.data_ptr(), 3 * D + PAD, D, ch.data_ptr(), cl.data_ptr(), B, H, N, 0.125, None)
     torch.cuda.synchronize()
     st = buf.cpu().numpy().reshape(nw, nt, 6)
     names = ["wait tile", "issue DMA", "K.Q^T", "softmax", "P.V", "loop"]
