@@ -14,8 +14,6 @@
 // bound by memory latency x occupancy and by vector-memory issue, so they are written around
 // their dependent-load chains: contributor / neighbour / slice records, requests of the next item behind the
 // gathers of the current one, results stored one item later.
-#include <hipcub/hipcub.hpp>
-
 #include <mutex>
 
 #include <stdlib.h>
@@ -875,12 +873,8 @@ __global__ void set_segments_kernel(const int* __restrict__ new_start, int M, in
 static inline int ok() { return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP; }
 
 size_t crf_sort_temp_bytes(size_t max_entries, int max_images) {
-    size_t a = 0, b = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                             (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)max_entries, 0, 64, 0);
     (void)max_images;
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int*)nullptr, (int*)nullptr, (int)max_entries, 0);
-    return (a > b ? a : b) + 256;
+    return sort_temp_bytes(max_entries) + 256;
 }
 
 // Build one lattice (D = 2: Gaussian xy/sxy ; D = 5: bilateral xy/sxy, rgb/srgb) for images [0,B).
@@ -900,14 +894,17 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     // bits actually populated: coordinates (D * BITS, low) + image index (IMG_SHIFT..)
     int img_bits = 0;
     while ((1 << img_bits) < B) img_bits++;
-    const int end_bit = B > 1 ? IMG_SHIFT + img_bits : (D == 2 ? 32 : 55);
-    size_t tb = temp_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(temp, tb, keys_a, keys_b, vals_a, L.vals, (int)ent_total, 0, end_bit, s) != hipSuccess)
-        return PNP_ERR_HIP;
+    // stable sort by (image, coordinates): the coordinate bits are [0, D * BITS), the image index sits at IMG_SHIFT (sort.hip;
+    // the inputs keys_a / vals_a are scratch from here on)
+    const int coord_bits = D == 2 ? 2 * KeyPack<2>::BITS : 5 * KeyPack<5>::BITS;
+    {
+        const int r = B > 1 ? radix_sort_pairs(keys_a, keys_b, vals_a, L.vals, ent_total, 0, coord_bits, IMG_SHIFT, IMG_SHIFT + img_bits, temp, temp_bytes, s)
+                            : radix_sort_pairs(keys_a, keys_b, vals_a, L.vals, ent_total, 0, coord_bits, 0, 0, temp, temp_bytes, s);
+        if (r != PNP_OK) return r;
+    }
     const int nbe = 1024;
     hipLaunchKernelGGL(mark_heads_kernel, dim3(nbe, B), dim3(256), 0, s, keys_b, d_imgs, D + 1, head);
-    tb = temp_bytes;
-    if (hipcub::DeviceScan::InclusiveSum(temp, tb, head, incl, (int)ent_total, s) != hipSuccess) return PNP_ERR_HIP;
+    if (device_scan_i32(head, incl, ent_total, true, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
     hipLaunchKernelGGL(scatter_ids_kernel, dim3(nbe, B), dim3(256), 0, s, keys_b, L.vals, head, incl, d_imgs, D + 1, B,
                        ent_total, L.offset, L.seg_start, L.ukeys, L.idbase);
     if (D == 2)
@@ -932,8 +929,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     hipLaunchKernelGGL(first_contrib_kernel, dim3(1024), dim3(256), 0, s, L.vals, L.seg_start, M, d_imgs, L.idbase, B, D + 1, fkey, fid);
     int img_bits2 = 0;
     while ((1 << img_bits2) < B) img_bits2++;
-    tb = temp_bytes;
-    if (hipcub::DeviceRadixSort::SortPairs(temp, tb, fkey, skey, fid, sid, M, 0, 40 + img_bits2, s) != hipSuccess) return PNP_ERR_HIP;
+    if (radix_sort_pairs(fkey, skey, fid, sid, (size_t)M, 0, 40 + img_bits2, 0, 0, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
     hipLaunchKernelGGL(rank_kernel, dim3(1024), dim3(256), 0, s, sid, M, rank);
     hipLaunchKernelGGL(renumber_points_kernel, dim3(1024), dim3(256), 0, s, rank, L.seg_start, n1k, n2k, L.cap, M, D + 1,
                        L.seg_lo, L.seg_hi, L.n1, L.n2);
@@ -943,8 +939,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     int* len = reinterpret_cast<int*>(keys_a);
     uint32_t* vals2 = reinterpret_cast<uint32_t*>(keys_b);
     hipLaunchKernelGGL(seg_len_kernel, dim3(1024), dim3(256), 0, s, L.seg_lo, L.seg_hi, M, len);
-    tb = temp_bytes;
-    if (hipcub::DeviceScan::ExclusiveSum(temp, tb, len, incl, M, s) != hipSuccess) return PNP_ERR_HIP;
+    if (device_scan_i32(len, incl, (size_t)M, false, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
     hipLaunchKernelGGL(move_segments_kernel, dim3(4096), dim3(256), 0, s, L.vals, incl, M, D + 1, L.bary, L.seg_lo, L.seg_hi, vals2, L.ent);
     hipLaunchKernelGGL(set_segments_kernel, dim3(1024), dim3(256), 0, s, incl, M, L.seg_lo, L.seg_hi);
     if (hipMemcpyAsync(L.vals, vals2, ent_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return PNP_ERR_HIP;

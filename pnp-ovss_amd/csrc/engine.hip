@@ -1669,6 +1669,31 @@ extern "C" int pnp_jpeg_decode(const uint8_t* d_data, const pnp_jpeg_image* d_im
                        (size_t)coef_elems, d_planes, d_rgb, max_blocks_per_image, max_pixels_per_image, d_err, (hipStream_t)stream);
 }
 
+// operator forms of the lattice build's sort / scan (tests); the scratch is allocated per call
+extern "C" int pnp_op_sort_pairs(uint64_t* d_keys_in, uint64_t* d_keys_out, uint32_t* d_vals_in, uint32_t* d_vals_out, int64_t n,
+                                 int32_t begin_bit, int32_t end_bit, void* stream) {
+    if (n < 0 || (n && (!d_keys_in || !d_keys_out || !d_vals_in || !d_vals_out))) return PNP_ERR_ARG;
+    if (!n) return PNP_OK;
+    const size_t tb = sort_temp_bytes((size_t)n);
+    void* temp = nullptr;
+    if (hipMalloc(&temp, tb) != hipSuccess) return PNP_ERR_NOMEM;
+    int r = radix_sort_pairs(d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, begin_bit, end_bit, 0, 0, temp, tb, (hipStream_t)stream);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && r == PNP_OK) r = PNP_ERR_HIP;
+    (void)hipFree(temp);
+    return r;
+}
+extern "C" int pnp_op_scan_i32(const int32_t* d_in, int32_t* d_out, int64_t n, int32_t inclusive, void* stream) {
+    if (n < 0 || (n && (!d_in || !d_out))) return PNP_ERR_ARG;
+    if (!n) return PNP_OK;
+    const size_t tb = sort_temp_bytes((size_t)n);
+    void* temp = nullptr;
+    if (hipMalloc(&temp, tb) != hipSuccess) return PNP_ERR_NOMEM;
+    int r = device_scan_i32(d_in, d_out, (size_t)n, inclusive != 0, temp, tb, (hipStream_t)stream);
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && r == PNP_OK) r = PNP_ERR_HIP;
+    (void)hipFree(temp);
+    return r;
+}
+
 extern "C" int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void* stream) {
     return cast_f32(to_bf16, d_in, d_out, (size_t)n, (hipStream_t)stream);
 }

@@ -1,0 +1,297 @@
+// Device-wide primitives of the DenseCRF lattice build (crf.hip), hand-written for gfx950: a STABLE least-significant-digit
+// radix sort of (64-bit key, 32-bit value) pairs and an int32 prefix sum.  Stability is part of the numerical contract: the
+// contributor list of a lattice point must stay in ascending pixel order so that the splat adds in the order of the sequential
+// CPU algorithm (oracle/densecrf_ref.c) -- a sort that is only "a" sort changes Q in the last bit.
+//
+// Sort: 8-bit digits, one pass per digit over [begin_bit, end_bit); per pass three launches --
+//   count   : every workgroup histograms the digit of its tile of 4096 items (one LDS atomic per item) -> hist[digit][tile]
+//   scan    : exclusive prefix sum over hist in (digit, tile) order = the first output slot of each (digit, tile) run
+//   scatter : the workgroup re-reads its tile in item order, ranks every item among the equal digits before it (wave: eight
+//             ballots; across the four waves and the 16 rounds of a tile: counters in LDS), lays the tile out sorted by digit in
+//             LDS and writes it out run by run -- consecutive lanes write consecutive addresses, ~16 items (128 B of keys) per run
+// HBM traffic per pass and item: keys read twice, value read once, both written once (36 B); 24 M entries x 8 passes ~ 7 GB.
+// The passes ping-pong between the caller's input and output arrays (the input is destroyed); an even pass count ends with
+// one copy.
+//
+// Scan: tiles of 8192 items (256 threads x 32), three phases -- tile sums, the scan of the tile sums (recursively; a single
+// workgroup below 8192 items), tile scan with its offset.
+#include <stdint.h>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace pnp {
+
+namespace {
+
+constexpr int kSortThreads = 256, kSortRounds = 16, kSortTile = kSortThreads * kSortRounds;   // 4096 items per workgroup
+constexpr int kScanThreads = 256, kScanIpt = 32, kScanTile = kScanThreads * kScanIpt;       // 8192 items per workgroup
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread workgroup; returns the exclusive prefix, *total = workgroup sum
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /* >= 4 ints */, int* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v, lane);
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / 64; w++) {
+        const int s = sh[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ---- scan ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kScanThreads) void scan_tile_sums_kernel(const int* __restrict__ in, size_t n, int* __restrict__ sums) {
+    __shared__ int sh[4];
+    const size_t t0 = (size_t)blockIdx.x * kScanTile;
+    int acc = 0;
+#pragma unroll 4
+    for (int i = 0; i < kScanIpt; i++) {
+        const size_t idx = t0 + (size_t)i * kScanThreads + threadIdx.x;
+        if (idx < n) acc += in[idx];
+    }
+    int tot;
+    (void)block_excl_scan(acc, sh, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// one tile: out = scan(in) + offset of the tile (offsets == nullptr: a single tile, offset 0).  A thread owns kScanIpt
+// CONSECUTIVE items (four 16-byte loads when the tile is full); the order of the additions does not matter for integers.
+template <bool INCLUSIVE>
+__global__ __launch_bounds__(kScanThreads) void scan_tile_kernel(const int* __restrict__ in, size_t n, const int* __restrict__ offsets,
+                                                                 int* __restrict__ out, int aligned16) {
+    __shared__ int sh[4];
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const size_t t0 = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanIpt;
+    const bool vec = aligned16 && t0 + kScanIpt <= n;          // 16-byte accesses on full, aligned runs
+    int v[kScanIpt];
+    int acc = 0;
+    if (vec) {
+#pragma unroll
+        for (int i = 0; i < kScanIpt / 4; i++) {
+            const i32x4 q = reinterpret_cast<const i32x4*>(in + t0)[i];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[i * 4 + e] = q[e];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanIpt; i++) v[i] = t0 + i < n ? in[t0 + i] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < kScanIpt; i++) acc += v[i];
+    int tot;
+    int run = block_excl_scan(acc, sh, &tot) + (offsets ? offsets[blockIdx.x] : 0);
+#pragma unroll
+    for (int i = 0; i < kScanIpt; i++) {
+        const int x = v[i];
+        v[i] = INCLUSIVE ? run + x : run;
+        run += x;
+    }
+    if (vec) {
+#pragma unroll
+        for (int i = 0; i < kScanIpt / 4; i++)
+            reinterpret_cast<i32x4*>(out + t0)[i] = i32x4{v[i * 4], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < kScanIpt; i++)
+            if (t0 + i < n) out[t0 + i] = v[i];
+    }
+}
+
+size_t scan_temp_ints(size_t n) {                   // tile sums of every level
+    size_t tot = 0;
+    while (n > (size_t)kScanTile) {
+        n = (n + kScanTile - 1) / kScanTile;
+        tot += (n + 63) / 64 * 64;
+    }
+    return tot;
+}
+
+int scan_rec(const int* in, int* out, size_t n, bool inclusive, int* temp, hipStream_t s) {
+    const int al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (n <= (size_t)kScanTile) {
+        if (inclusive) hipLaunchKernelGGL((scan_tile_kernel<true>), dim3(1), dim3(kScanThreads), 0, s, in, n, (const int*)nullptr, out, al);
+        else hipLaunchKernelGGL((scan_tile_kernel<false>), dim3(1), dim3(kScanThreads), 0, s, in, n, (const int*)nullptr, out, al);
+        return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+    }
+    const size_t nt = (n + kScanTile - 1) / kScanTile;
+    int* sums = temp;
+    hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)nt), dim3(kScanThreads), 0, s, in, n, sums);
+    const int r = scan_rec(sums, sums, nt, false, temp + (nt + 63) / 64 * 64, s);      // in place: tile offsets
+    if (r != PNP_OK) return r;
+    if (inclusive) hipLaunchKernelGGL((scan_tile_kernel<true>), dim3((unsigned)nt), dim3(kScanThreads), 0, s, in, n, (const int*)sums, out, al);
+    else hipLaunchKernelGGL((scan_tile_kernel<false>), dim3((unsigned)nt), dim3(kScanThreads), 0, s, in, n, (const int*)sums, out, al);
+    return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+// ---- radix sort ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void sort_count_kernel(const uint64_t* __restrict__ keys, size_t n, int shift, int ntiles,
+                                                                  int* __restrict__ hist) {
+    __shared__ int cnt[256];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t t0 = (size_t)blockIdx.x * kSortTile;
+#pragma unroll 4
+    for (int r = 0; r < kSortRounds; r++) {
+        const size_t idx = t0 + (size_t)r * kSortThreads + threadIdx.x;
+        if (idx < n) atomicAdd(&cnt[(int)((keys[idx] >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = cnt[threadIdx.x];       // digit-major: the scan order of the pass
+}
+
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                                    size_t n, int shift, int ntiles, const int* __restrict__ hist_scanned,
+                                                                    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint64_t skey[kSortTile];            // 32 KB: the tile sorted by digit
+    __shared__ uint32_t sval[kSortTile];            // 16 KB
+    __shared__ int wcnt[4][256];                    // items of each digit per wave, this round
+    __shared__ int run[256];                        // items of each digit in the rounds before this one
+    __shared__ int gbase[256];                      // first output slot of this tile's run of each digit
+    __shared__ int sh[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t t0 = (size_t)blockIdx.x * kSortTile;
+    const int tile_n = (int)((n - t0) < (size_t)kSortTile ? (n - t0) : (size_t)kSortTile);
+
+    // digit counts of the tile (recounted: 4096 LDS atomics are cheaper than a second global array) -> local starts
+    run[tid] = 0;
+    __syncthreads();
+    uint64_t k[kSortRounds];
+    uint32_t v[kSortRounds];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; r++) {
+        const int i = r * kSortThreads + tid;
+        k[r] = 0;
+        v[r] = 0;
+        if (i < tile_n) {
+            k[r] = keys[t0 + i];
+            v[r] = vals[t0 + i];
+            atomicAdd(&run[(int)((k[r] >> shift) & 255)], 1);
+        }
+    }
+    __syncthreads();
+    {
+        const int c = run[tid];
+        int tot;
+        const int ex = block_excl_scan(c, sh, &tot);
+        gbase[tid] = hist_scanned[(size_t)tid * ntiles + blockIdx.x] - ex;       // global slot of sorted-tile slot j: gbase[d] + j
+        run[tid] = ex;                              // running slot of the digit: start + items placed so far
+    }
+#pragma unroll
+    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
+    __syncthreads();
+
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int r = 0; r < kSortRounds; r++) {
+        const int i = r * kSortThreads + tid;
+        const bool on = i < tile_n;
+        const int d = on ? (int)((k[r] >> shift) & 255) : 0;
+        // lanes of this wave holding the same digit (inactive lanes drop out through the `on` ballot)
+        uint64_t peers = __ballot(on);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        const int before = __popcll(peers & lt);
+        if (on && before == 0) wcnt[wave][d] = __popcll(peers);                  // the group's first lane
+        __syncthreads();
+        if (on) {
+            int slot = run[d] + before;
+#pragma unroll
+            for (int w = 0; w < 3; w++)
+                if (w < wave) slot += wcnt[w][d];
+            skey[slot] = k[r];
+            sval[slot] = v[r];
+        }
+        __syncthreads();
+        {   // thread d closes the round for digit d
+            run[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+#pragma unroll
+            for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
+        }
+        __syncthreads();
+    }
+    // the sorted tile leaves run by run: slot j belongs to digit (key >> shift) & 255, its output slot is gbase[digit] + j
+#pragma unroll 4
+    for (int r = 0; r < kSortRounds; r++) {
+        const int j = r * kSortThreads + tid;
+        if (j < tile_n) {
+            const uint64_t kk = skey[j];
+            const size_t g = (size_t)(gbase[(int)((kk >> shift) & 255)] + j);
+            keys_out[g] = kk;
+            vals_out[g] = sval[j];
+        }
+    }
+}
+
+}  // namespace
+
+size_t sort_temp_bytes(size_t n) {
+    const size_t ntiles = (n + kSortTile - 1) / kSortTile;
+    const size_t hist = (256 * ntiles + 63) / 64 * 64;
+    const size_t a = hist + scan_temp_ints(256 * ntiles);       // sort: histogram + its scan's tile sums
+    const size_t b = scan_temp_ints(n);                         // a scan over n items
+    return ((a > b ? a : b) + 64) * sizeof(int);
+}
+
+int device_scan_i32(const int* in, int* out, size_t n, bool inclusive, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (!n) return PNP_OK;
+    if (n >= ((size_t)1 << 31) || scan_temp_ints(n) * sizeof(int) > temp_bytes) return PNP_ERR_ARG;
+    return scan_rec(in, out, n, inclusive, reinterpret_cast<int*>(temp), s);
+}
+
+// Sorts (keys_in, vals_in)[0, n) by the key bits [begin_bit, end_bit) and, above them, [begin2, end2) (empty when end2 <= begin2;
+// the bits between the two ranges must be equal in all keys: the Gaussian lattice's keys are 32 coordinate bits and the image
+// index at bit 55) into (keys_out, vals_out); stable; destroys the inputs.
+int radix_sort_pairs(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int begin_bit, int end_bit,
+                     int begin2, int end2, void* temp, size_t temp_bytes, hipStream_t s) {
+    if (!n) return PNP_OK;
+    if (n >= ((size_t)1 << 31) || end_bit <= begin_bit || end_bit > 64 || end2 > 64 || (end2 > begin2 && begin2 < end_bit) ||
+        sort_temp_bytes(n) > temp_bytes)
+        return PNP_ERR_ARG;
+    const int ntiles = (int)((n + kSortTile - 1) / kSortTile);
+    const size_t nh = (size_t)256 * ntiles;
+    int* hist = reinterpret_cast<int*>(temp);
+    int* scan_tmp = hist + (nh + 63) / 64 * 64;
+    uint64_t* kin = keys_in;
+    uint64_t* kout = keys_out;
+    uint32_t* vin = vals_in;
+    uint32_t* vout = vals_out;
+    int shifts[16], np = 0;                          // a digit may reach past its range into bits that are equal in all keys
+    for (int b = begin_bit; b < end_bit; b += 8) shifts[np++] = b;
+    for (int b = begin2; b < end2; b += 8) shifts[np++] = b;
+    for (int i = 0; i < np; i++) {
+        const int shift = shifts[i];
+        hipLaunchKernelGGL(sort_count_kernel, dim3(ntiles), dim3(kSortThreads), 0, s, (const uint64_t*)kin, n, shift, ntiles, hist);
+        const int r = scan_rec(hist, hist, nh, false, scan_tmp, s);
+        if (r != PNP_OK) return r;
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, s, (const uint64_t*)kin, (const uint32_t*)vin, n, shift,
+                           ntiles, (const int*)hist, kout, vout);
+        uint64_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    if (hipGetLastError() != hipSuccess) return PNP_ERR_HIP;
+    if (kin != keys_out) {                          // even number of passes: the result sits in the input arrays
+        if (hipMemcpyAsync(keys_out, kin, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return PNP_ERR_HIP;
+        if (hipMemcpyAsync(vals_out, vin, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return PNP_ERR_HIP;
+    }
+    return PNP_OK;
+}
+
+}  // namespace pnp

@@ -93,6 +93,8 @@ def load_library():
         "pnp_op_gemm_x3a": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, i32, vp]),
         "pnp_dbg_gemm_stamps": (i32, [vp, i32]),
         "pnp_op_xattn": (i32, [i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+        "pnp_op_sort_pairs": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+        "pnp_op_scan_i32": (i32, [vp, vp, i64, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = ABI drift, fail loudly
@@ -109,7 +111,7 @@ EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes"
             "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images",
             "pnp_cross_kv", "pnp_profile_read_stage", "pnp_op_split", "pnp_op_gemm_x3", "pnp_op_gemm_x3a",
             "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer", "pnp_allocated_bytes",
-            "pnp_op_vit_attention_x3", "pnp_jpeg_decode"]
+            "pnp_op_vit_attention_x3", "pnp_jpeg_decode", "pnp_op_sort_pairs", "pnp_op_scan_i32"]
 
 
 class _DevView:

@@ -71,6 +71,62 @@ def _nerr(tag, got, ref, reduce="max"):
 
 
 # ------------------------------------------------------------------------------------------ operators
+def _lib():
+    from pnp_ovss import hip
+    return hip.load_library()
+
+
+@pytest.mark.parametrize("n", [1, 255, 4096, 4097, 70001, 3_000_001])
+@pytest.mark.parametrize("bits", [(0, 8), (0, 32), (0, 61), (3, 46)])
+def test_lattice_sort_pairs_is_a_stable_sort(n, bits):
+    """csrc/sort.hip against numpy's stable argsort on the selected key bits: equal keys keep their input order (the order
+    the DenseCRF splat adds a lattice point's contributors in; crf.hip header).  Few distinct keys (heavy ties), keys with
+    one digit populated, and random keys."""
+    lib = _lib()
+    lo, hi = bits
+    rng = np.random.default_rng(n * 131 + hi)
+    mask = (np.uint64(1) << np.uint64(hi)) - np.uint64(1) if hi < 64 else np.uint64(2**64 - 1)
+    for kind in ("random", "ties", "one_digit"):
+        if kind == "random":
+            keys = rng.integers(0, 2**63, size=n, dtype=np.uint64) & mask
+        elif kind == "ties":
+            keys = (rng.integers(0, 7, size=n, dtype=np.uint64) << np.uint64(lo + 1)) & mask
+        else:
+            keys = (rng.integers(0, 256, size=n, dtype=np.uint64) << np.uint64(min(hi - 1, lo + 16))) & mask
+        vals = np.arange(n, dtype=np.uint32)
+        sel = (keys >> np.uint64(lo)) & ((np.uint64(1) << np.uint64(hi - lo)) - np.uint64(1))
+        order = np.argsort(sel, kind="stable")
+        kin, vin = _dev(keys.view(np.int64)), _dev(vals.view(np.int32))
+        kout, vout = torch.empty_like(kin), torch.empty_like(vin)
+        assert lib.pnp_op_sort_pairs(kin.data_ptr(), kout.data_ptr(), vin.data_ptr(), vout.data_ptr(), n, lo, hi, None) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(vout.cpu().numpy().view(np.uint32), vals[order], err_msg=f"{kind} n={n} bits={bits}")
+        np.testing.assert_array_equal(kout.cpu().numpy().view(np.uint64), keys[order])
+
+
+@pytest.mark.parametrize("n", [1, 31, 8192, 8193, 100_003, 70_000_000])
+@pytest.mark.parametrize("inclusive", [0, 1])
+def test_lattice_scan_i32(n, inclusive):
+    """csrc/sort.hip prefix sum (segment heads -> lattice ids, segment lengths -> list offsets) against numpy, incl. a size that
+    needs three levels and an unaligned slice (element-wise path)."""
+    lib = _lib()
+    rng = np.random.default_rng(n + inclusive)
+    x = rng.integers(0, 3, size=n + 1, dtype=np.int32)
+    for off in (0, 1):
+        a = x[off:off + n] if off else x[:n]
+        d_all = _dev(x)
+        d_in = d_all[off:off + n]
+        d_out = torch.empty(n + 1, dtype=torch.int32, device="cuda")[off:off + n]
+        assert lib.pnp_op_scan_i32(d_in.data_ptr(), d_out.data_ptr(), n, inclusive, None) == 0
+        ref = np.cumsum(a, dtype=np.int64)
+        if not inclusive:
+            ref = ref - a
+        np.testing.assert_array_equal(d_out.cpu().numpy().astype(np.int64), ref)
+    assert lib.pnp_op_scan_i32(None, None, 0, 1, None) == 0
+    assert lib.pnp_op_sort_pairs(None, None, None, None, 0, 0, 8, None) == 0
+    assert lib.pnp_op_sort_pairs(None, None, None, None, 5, 0, 8, None) != 0
+
+
 
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("shape", [(300, 256, 128), (2048, 1536, 256), (77, 64, 1024)])
