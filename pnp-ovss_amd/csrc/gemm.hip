@@ -796,9 +796,11 @@ static int launch_wide(const GemmArgs& g, hipStream_t s) {
 // KS = k32 steps per slab (1: 32-deep, 64-byte LDS rows; 2: 64-deep, 128-byte rows swizzled like the wide bf16 kernel): these
 // launches move ~260 MB through L2 for a few GFLOP and run at the latency x bytes-in-flight of the CUs they occupy (168-672
 // workgroups), so the deeper slab (twice the bytes in flight per workgroup, half the barriers) is what the product launches.
-template <int NW, int KS>
+template <int NW, int KS, int NS = 4>
 __global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArgs g) {
-    constexpr int BM = 64, BN = 64, ROWB = 64 * KS, ARR = 64 * ROWB, SLOT = 4 * ARR, NS = 4;
+    constexpr int BM = 64, BN = 64, ROWB = 64 * KS, ARR = 64 * ROWB, SLOT = 4 * ARR;
+    constexpr int LEAD = NS - 1;                       // slabs in flight ahead of the one being multiplied (3 | 2)
+    static_assert(NS == 3 || NS == 4, "ring depth");
     constexpr int WN = NW / 2, TN = 2 / (NW / 4);      // waves along n, 16-column tiles per wave (2 | 1); 2 row tiles per wave
     constexpr int EPT = 32 * KS / NW;                  // staged A values per thread and slab (NW threads per row)
     constexpr int PROWS = 1024 / ROWB;                 // rows of a 1 KB DMA piece (16 | 8)
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArg
     const int fa_row = (wm * 32 + r) * ROWB, fb_row = 2 * ARR + (wn * 16 * TN + r) * ROWB;
     const int fsw = swz(r);
 
-    // prologue: slab 0 (A written at once); slabs 1 and 2 in flight (A in registers, B by DMA)
+    // prologue: slab 0 (A written at once); slabs 1 .. LEAD - 1 in flight (A in registers, B by DMA)
     load_a(0);
     issue_b(0);
     store_a(0);
@@ -901,7 +903,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArg
         load_a(1);
         issue_b(1);
     }
-    if (nk > 2) {
+    if (LEAD > 2 && nk > 2) {
         load_a(2);
         issue_b(2);
     }
@@ -910,8 +912,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArg
         constexpr int REST = decltype(rest)::value;
         // slab kt complete for everybody: own B pieces of slab kt landed and the A values of slab kt + 1 loaded; still in
         // flight (issue order): B(kt+1) | A(kt+2), B(kt+2)
-        if constexpr (REST >= 2) PNP_WAIT_VM_LGKM(BP + VMI);
-        else if constexpr (REST == 1) PNP_WAIT_VM_LGKM(BP);
+        if constexpr (REST >= 2 && LEAD == 3) PNP_WAIT_VM_LGKM(BP + VMI);
+        else if constexpr (REST >= 1) PNP_WAIT_VM_LGKM(BP);
         else PNP_WAIT_VM_LGKM(0);
         __builtin_amdgcn_s_barrier();
         // fragment reads first: their latency runs under the conversion of the next slab's A values
@@ -931,10 +933,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArg
                 bl[ks][i] = *reinterpret_cast<const bf16x8*>(st + ARR + fb_row + i * 16 * ROWB + co);
             }
         }
-        if constexpr (REST >= 1) store_a(kt + 1);     // slot (kt+1) % 4 was last read in iteration kt-3
-        if constexpr (REST >= 3) {
-            load_a(kt + 3);                           // into the register set store_a has just emptied
-            issue_b(kt + 3);                          // slot (kt+3) % 4 was last read in iteration kt-1: free since this barrier
+        if constexpr (REST >= 1) store_a(kt + 1);     // slot (kt+1) % NS was last read in iteration kt + 1 - NS
+        if constexpr (REST >= LEAD) {
+            load_a(kt + LEAD);                        // (LEAD = 3: into the register set store_a has just emptied)
+            issue_b(kt + LEAD);                       // slot (kt+LEAD) % NS was last read in iteration kt-1: free since this barrier
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ks++)
@@ -952,8 +954,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArg
     constexpr std::integral_constant<int, 1> r1{};
     constexpr std::integral_constant<int, 0> r0{};
     int kt = 0;
-    for (; kt + 4 < nk; kt += 2) {                    // two iterations per trip: the register set indices are compile-time
-        iter(kt, r3);
+    for (; kt + LEAD + 1 < nk; kt += 2) {             // two iterations per trip: the register set indices are compile-time
+        iter(kt, r3);                                 // (REST >= LEAD is all the steady state needs to know)
         iter(kt + 1, r3);
     }
     for (; kt < nk; kt++) {                           // the last (up to four) slabs
@@ -977,23 +979,31 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_small_x3_kernel(const GemmArg
     }
 }
 
-template <int NW, int KS>
+template <int NW, int KS, int NS = 4>
 static int launch_small_x3_t(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 63) / 64, nbn = g.N / 64;
-    constexpr int smem = 4 * 4 * 64 * 64 * KS;
+    constexpr int smem = NS * 4 * 64 * 64 * KS;
     // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small_x3_kernel<NW, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small_x3_kernel<NW, KS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (attr != hipSuccess) return PNP_ERR_HIP;
-    hipLaunchKernelGGL((gemm_nt_small_x3_kernel<NW, KS>), dim3(nbm * nbn), dim3(NW * 64), smem, s, g);
+    hipLaunchKernelGGL((gemm_nt_small_x3_kernel<NW, KS, NS>), dim3(nbm * nbn), dim3(NW * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
 
 static int launch_small_x3(const GemmArgs& g, hipStream_t s) {
     int nw = 8, ks = g.K % 64 == 0 ? 2 : 1;
+    // many more workgroups than CUs (the N = 3072 launches at M = 875: 672): three co-resident workgroups per CU on 48 KB rings
+    // (3 slots of 32-deep slabs) run the launch as ONE round instead of three rounds of one 128 KB workgroup per CU: 28.9 -> 25.2 us.
+    // Not more than that, and nothing at 504 workgroups (21.2 against 21.4 us) or on the deep-K shapes (58 against 29 us): these
+    // launches run at what a CU ingests from L2 (~20-27 B/clk, tools/micro/lds_dma_rate.hip), whoever is resident on it.
+    int variant = (long)((g.M + 63) / 64) * (g.N / 64) > 600 && g.K <= 1024 ? 1 : 0;
 #ifdef PNP_DEV
     if (getenv("PNP_SMALL_NW")) nw = atoi(getenv("PNP_SMALL_NW"));
     if (getenv("PNP_SMALL_KS") && atoi(getenv("PNP_SMALL_KS")) == 1) ks = 1;
+    if (getenv("PNP_SMALL_VARIANT")) variant = atoi(getenv("PNP_SMALL_VARIANT"));
 #endif
+    if (variant == 1) return launch_small_x3_t<8, 1, 3>(g, s);
+    if (variant == 2) return launch_small_x3_t<8, 2, 3>(g, s);          // 96 KB: one per CU, for comparison
     if (ks == 2) return nw == 4 ? launch_small_x3_t<4, 2>(g, s) : launch_small_x3_t<8, 2>(g, s);
     return nw == 4 ? launch_small_x3_t<4, 1>(g, s) : launch_small_x3_t<8, 1>(g, s);
 }
