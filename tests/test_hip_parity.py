@@ -246,7 +246,7 @@ def _x3_case(kind, M, N, K, tok=None):
     assert err < 0.05 * float((one - want).abs().max())
 
 
-@pytest.mark.parametrize("shape", [(875, 768, 768), (875, 2304, 768), (875, 768, 3072), (130, 3072, 768), (1, 768, 32), (64, 64, 2304)])
+@pytest.mark.parametrize("shape", [(875, 768, 768), (875, 2304, 768), (875, 768, 3072), (875, 3072, 768), (130, 3072, 768), (1, 768, 32), (64, 64, 2304)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_split_bf16_text_side(shape, mode):
     """The text-side split-bf16 Linear (gemm_nt_small_x3_kernel): fp32 activations split by the kernel, weight as a (hi, lo)
