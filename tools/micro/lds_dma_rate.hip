@@ -11,12 +11,12 @@
 // each wave: REPS rounds of PIECES pieces; piece = 8 rows x 128 B at `stride` bytes (mode 0) or 1 KiB contiguous (stride = 128)
 template <int MODE>   // 0 = LDS-DMA, 1 = global_load -> VGPR -> ds_write, 2 = global_load -> VGPR only
 __global__ __launch_bounds__(512) void k(const char* __restrict__ src, size_t wg_bytes, int stride, int pieces, int reps,
-                                         unsigned long long* out, float* sink, int cold) {
+                                         unsigned long long* out, float* sink, int cold, int lpr) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nw = blockDim.x >> 6;
     const char* base = cold ? src + (size_t)blockIdx.x * (4u << 20) : src + (size_t)(blockIdx.x % 64) * wg_bytes;   // hot: 64 regions, cache resident
-    const uint32_t loff = (uint32_t)(lane >> 3) * stride + (lane & 7) * 16;
+    const uint32_t loff = (uint32_t)(lane / lpr) * stride + (lane % lpr) * 16;      // lpr lanes (16 B each) per row: 8 = 128-byte rows, 4 = 64-byte rows
     float acc = 0.f;
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -25,9 +25,10 @@ __global__ __launch_bounds__(512) void k(const char* __restrict__ src, size_t wg
         const unsigned long long ti0 = __builtin_readcyclecounter();
         for (int p = 0; p < pieces; p++) {
             const int pi = wave * pieces + p;
+            const int rpp = 64 / lpr;                                           // rows per piece
             const uint32_t lin = (uint32_t)((r * nw + wave) * pieces + p);      // cold: every piece of the launch at its own address
-            const char* sb = cold ? base + ((lin * 8u * (uint32_t)stride + (lin * 8u * (uint32_t)stride >> 22) * 128u) & ((4u << 20) - 1 - 65536))
-                                  : base + (((uint32_t)pi * 8u * (uint32_t)stride) & (uint32_t)(wg_bytes / 2 - 1));
+            const char* sb = cold ? base + ((lin * rpp * (uint32_t)stride + (lin * rpp * (uint32_t)stride >> 22) * 128u) & ((4u << 20) - 1 - 65536))
+                                  : base + (((uint32_t)pi * rpp * (uint32_t)stride + (lpr == 4 ? (uint32_t)(r & 1) * 64u : 0u)) & (uint32_t)(wg_bytes / 2 - 1));
             char* dst = lds + (size_t)pi * 1024;
             if constexpr (MODE == 0) {
                 const uint32_t l = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
@@ -73,15 +74,16 @@ int main() {
     CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
     const int reps = 32;
     for (int cold = 0; cold < 2; cold++)
-    for (int stride : {128, 6144}) {
-        for (int nw : {1, 2, 4, 8}) {
+    for (int lpr : {8, 4})
+    for (int stride : {lpr * 16, 2048, 6144}) {
+        for (int nw : {4, 8}) {
             const int pieces = 64 / nw > 16 ? 16 : 64 / nw;       // <= 64 KiB of LDS targets per workgroup
-            for (int mode = 0; mode < 3; mode++) {
+            for (int mode = 0; mode < 2; mode++) {
                 std::vector<unsigned long long> h(256 * nw), hi(256 * nw);
                 for (int it = 0; it < 2; it++) {
-                    if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(nw * 64), 131072, 0, src, wg_bytes, stride, pieces, reps, out, sink, cold);
-                    if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(nw * 64), 131072, 0, src, wg_bytes, stride, pieces, reps, out, sink, cold);
-                    if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(nw * 64), 131072, 0, src, wg_bytes, stride, pieces, reps, out, sink, cold);
+                    if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(nw * 64), 131072, 0, src, wg_bytes, stride, pieces, reps, out, sink, cold, lpr);
+                    if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(nw * 64), 131072, 0, src, wg_bytes, stride, pieces, reps, out, sink, cold, lpr);
+                    if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(nw * 64), 131072, 0, src, wg_bytes, stride, pieces, reps, out, sink, cold, lpr);
                     CHK(hipDeviceSynchronize());
                 }
                 CHK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));
@@ -92,7 +94,7 @@ int main() {
                 mx /= h.size();
                 mi /= hi.size();
                 const double bytes = (double)nw * pieces * reps * 1024.0;
-                printf("%s stride %5d B  waves %d  pieces/wave/round %2d  %s: %7.1f cycles per piece per wave (issue alone %6.1f), %6.1f B/clk per CU\n", cold ? "cold" : "hot ", stride, nw, pieces,
+                printf("%s rows of %3d B, stride %5d B  waves %d  pieces/wave/round %2d  %s: %7.1f cycles per piece per wave (issue alone %6.1f), %6.1f B/clk per CU\n", cold ? "cold" : "hot ", lpr * 16, stride, nw, pieces,
                        mode == 0 ? "LDS-DMA        " : mode == 1 ? "VGPR + ds_write" : "VGPR only      ", mx / (pieces * reps), mi / (pieces * reps), bytes / mx);
             }
         }
