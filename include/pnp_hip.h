@@ -313,9 +313,11 @@ int pnp_op_cast(int32_t to_bf16, const float* d_in, void* d_out, int64_t n, void
  * hash table, PnP_OVSS_0514_updated_segmentation.py:1066-1070: here the lattice is built by a STABLE radix sort of the
  * (pixel, vertex) keys and prefix sums, csrc/sort.hip).  pnp_op_sort_pairs sorts n (u64 key, u32 value) pairs by the key
  * bits [begin_bit, end_bit) into d_keys_out / d_vals_out, equal keys keeping their input order; the input arrays are
- * overwritten.  pnp_op_scan_i32: d_out[i] = sum of d_in[0..i] (inclusive) or d_in[0..i-1] (exclusive); in place allowed. */
+ * overwritten.  h_seg_off (HOST array of n_seg + 1 ascending item offsets from 0 to n, n_seg <= 64; NULL = one segment):
+ * the items of a segment are sorted among themselves and stay in its range (the images of a batch).
+ * pnp_op_scan_i32: d_out[i] = sum of d_in[0..i] (inclusive) or d_in[0..i-1] (exclusive); in place allowed. */
 int pnp_op_sort_pairs(uint64_t* d_keys_in, uint64_t* d_keys_out, uint32_t* d_vals_in, uint32_t* d_vals_out, int64_t n,
-                      int32_t begin_bit, int32_t end_bit, void* stream);
+                      int32_t begin_bit, int32_t end_bit, const size_t* h_seg_off, int32_t n_seg, void* stream);
 int pnp_op_scan_i32(const int32_t* d_in, int32_t* d_out, int64_t n, int32_t inclusive, void* stream);
 
 #ifdef __cplusplus

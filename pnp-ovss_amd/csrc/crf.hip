@@ -879,7 +879,7 @@ size_t crf_sort_temp_bytes(size_t max_entries, int max_images) {
 
 // Build one lattice (D = 2: Gaussian xy/sxy ; D = 5: bilateral xy/sxy, rgb/srgb) for images [0,B).
 // Scratch arrays (keys/vals double buffers, head, incl, temp) are caller-provided.
-int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
+int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const PostDesc* h_imgs, const uint8_t* d_rgb, float sxy, float srgb,
                       int B, size_t ent_total, int max_pixels,
                       uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
                       void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, int* h_points, hipStream_t s) {
@@ -892,14 +892,19 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
         return PNP_ERR_ARG;
     if (B > (1 << IMG_BITS)) return PNP_ERR_ARG;
     // bits actually populated: coordinates (D * BITS, low) + image index (IMG_SHIFT..)
-    int img_bits = 0;
-    while ((1 << img_bits) < B) img_bits++;
-    // stable sort by (image, coordinates): the coordinate bits are [0, D * BITS), the image index sits at IMG_SHIFT (sort.hip;
-    // the inputs keys_a / vals_a are scratch from here on)
+    // stable sort by (image, coordinates).  The entries of image b are the run [pix0 * (D+1), (pix0 + H W) * (D+1)) on entry, so
+    // the sort is segmented by image over the coordinate bits [0, D * BITS) alone (sort.hip; the image bits at IMG_SHIFT stay in
+    // the keys for the kernels below; the inputs keys_a / vals_a are scratch from here on)
     const int coord_bits = D == 2 ? 2 * KeyPack<2>::BITS : 5 * KeyPack<5>::BITS;
+    size_t seg_off[(1 << IMG_BITS) + 1];
+    for (int b = 0; b < B; b++) {
+        seg_off[b] = (size_t)h_imgs[b].pix0 * (D + 1);
+        if (b && seg_off[b] != seg_off[b - 1] + (size_t)h_imgs[b - 1].H * h_imgs[b - 1].W * (D + 1)) return PNP_ERR_ARG;
+    }
+    seg_off[B] = ent_total;
+    if (B < 1 || seg_off[0] != 0 || seg_off[B - 1] + (size_t)h_imgs[B - 1].H * h_imgs[B - 1].W * (D + 1) != ent_total) return PNP_ERR_ARG;
     {
-        const int r = B > 1 ? radix_sort_pairs(keys_a, keys_b, vals_a, L.vals, ent_total, 0, coord_bits, IMG_SHIFT, IMG_SHIFT + img_bits, temp, temp_bytes, s)
-                            : radix_sort_pairs(keys_a, keys_b, vals_a, L.vals, ent_total, 0, coord_bits, 0, 0, temp, temp_bytes, s);
+        const int r = radix_sort_pairs(keys_a, keys_b, vals_a, L.vals, ent_total, 0, coord_bits, seg_off, B, temp, temp_bytes, s);
         if (r != PNP_OK) return r;
     }
     const int nbe = 1024;
@@ -913,11 +918,13 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
         hipLaunchKernelGGL((neighbors_kernel<5>), dim3(nbe, B), dim3(256), 0, s, L.ukeys, L.idbase, L.cap, n1k, n2k);
     // spatial renumbering (needs the lattice size on the host: one small read-back per build)
     int M = 0;
+    int h_idbase[(1 << IMG_BITS) + 1];                    // first lattice id of every image (the second sort's segments)
     // (the key-range flag of the embed kernel rides on the same synchronisation)
     int err = 0;
-    if (hipMemcpyAsync(&M, L.idbase + B, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return PNP_ERR_HIP;
+    if (hipMemcpyAsync(h_idbase, L.idbase, sizeof(int) * (B + 1), hipMemcpyDeviceToHost, s) != hipSuccess) return PNP_ERR_HIP;
     if (hipMemcpyAsync(&err, d_range_err, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return PNP_ERR_HIP;
     if (hipStreamSynchronize(s) != hipSuccess) return PNP_ERR_HIP;
+    M = h_idbase[B];
     if (err && h_range_err) *h_range_err = 1;
     if (M <= 0 || (size_t)M > ent_total) return PNP_ERR_STATE;
     if (h_points) *h_points = M;                          // lattice points of the batch (bench.py: lattice term of the byte model)
@@ -927,9 +934,11 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     uint32_t* sid = reinterpret_cast<uint32_t*>(incl);    // (rewritten by the segment scan below)
     int* rank = head;
     hipLaunchKernelGGL(first_contrib_kernel, dim3(1024), dim3(256), 0, s, L.vals, L.seg_start, M, d_imgs, L.idbase, B, D + 1, fkey, fid);
-    int img_bits2 = 0;
-    while ((1 << img_bits2) < B) img_bits2++;
-    if (radix_sort_pairs(fkey, skey, fid, sid, (size_t)M, 0, 40 + img_bits2, 0, 0, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
+    {   // lattice points are numbered image by image: segmented by image over (Z-order position, vertex) = bits [0, 40)
+        size_t seg2[(1 << IMG_BITS) + 1];
+        for (int b = 0; b <= B; b++) seg2[b] = (size_t)h_idbase[b];
+        if (radix_sort_pairs(fkey, skey, fid, sid, (size_t)M, 0, 40, seg2, B, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
+    }
     hipLaunchKernelGGL(rank_kernel, dim3(1024), dim3(256), 0, s, sid, M, rank);
     hipLaunchKernelGGL(renumber_points_kernel, dim3(1024), dim3(256), 0, s, rank, L.seg_start, n1k, n2k, L.cap, M, D + 1,
                        L.seg_lo, L.seg_hi, L.n1, L.n2);

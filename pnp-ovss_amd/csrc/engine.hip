@@ -1259,7 +1259,7 @@ extern "C" int pnp_post_prepare(pnp_engine* e, const pnp_post_batch* b, int32_t 
             // the Gaussian (xy-only) lattice depends on the image sizes alone: keep it across batches
             if (t == 0 && sig == p.gauss_sig) continue;
             const int D1 = t == 0 ? 3 : 6;
-            KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
+            KCHK(e, crf_build_lattice(D1 - 1, p.lat[t], p.d_desc, p.desc.data(), p.d_rgb, t == 0 ? 3.0f : 50.0f, 5.0f, B, (size_t)pix * D1,
                                       p.maxHW, p.keys_a, p.keys_b, p.vals_a, p.head, p.incl,
                                       p.n1k, p.n2k, p.sort_tmp, p.sort_tmp_bytes, p.range_err, &p.range_err_host, &p.lat_points[t], s));
             KCHK(e, crf_lattice_norm(p.lat[t], p.d_desc, B, p.maxHW, (size_t)pix * D1, p.va, p.vb, p.norm[t], s));
@@ -1671,13 +1671,13 @@ extern "C" int pnp_jpeg_decode(const uint8_t* d_data, const pnp_jpeg_image* d_im
 
 // operator forms of the lattice build's sort / scan (tests); the scratch is allocated per call
 extern "C" int pnp_op_sort_pairs(uint64_t* d_keys_in, uint64_t* d_keys_out, uint32_t* d_vals_in, uint32_t* d_vals_out, int64_t n,
-                                 int32_t begin_bit, int32_t end_bit, void* stream) {
+                                 int32_t begin_bit, int32_t end_bit, const size_t* h_seg_off, int32_t n_seg, void* stream) {
     if (n < 0 || (n && (!d_keys_in || !d_keys_out || !d_vals_in || !d_vals_out))) return PNP_ERR_ARG;
     if (!n) return PNP_OK;
     const size_t tb = sort_temp_bytes((size_t)n);
     void* temp = nullptr;
     if (hipMalloc(&temp, tb) != hipSuccess) return PNP_ERR_NOMEM;
-    int r = radix_sort_pairs(d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, begin_bit, end_bit, 0, 0, temp, tb, (hipStream_t)stream);
+    int r = radix_sort_pairs(d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, begin_bit, end_bit, h_seg_off, n_seg, temp, tb, (hipStream_t)stream);
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess && r == PNP_OK) r = PNP_ERR_HIP;
     (void)hipFree(temp);
     return r;

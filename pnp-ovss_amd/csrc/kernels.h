@@ -140,10 +140,10 @@ int jpeg_decode(const uint8_t* d_data, const JpegImage* d_imgs, const JpegTables
 // sort.hip: stable LSD radix sort of (u64 key, u32 value) pairs and int32 prefix sum (the lattice build's device-wide primitives)
 size_t sort_temp_bytes(size_t n);
 int radix_sort_pairs(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int begin_bit, int end_bit,
-                     int begin2, int end2, void* temp, size_t temp_bytes, hipStream_t s);
+                     const size_t* seg_off, int nseg, void* temp, size_t temp_bytes, hipStream_t s);
 int device_scan_i32(const int* in, int* out, size_t n, bool inclusive, void* temp, size_t temp_bytes, hipStream_t s);
 size_t crf_sort_temp_bytes(size_t max_entries, int max_images);
-int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const uint8_t* d_rgb, float sxy, float srgb,
+int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const PostDesc* h_imgs, const uint8_t* d_rgb, float sxy, float srgb,
                       int B, size_t ent_total, int max_pixels,
                       uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, int* head, int* incl, int* n1k, int* n2k,
                       void* temp, size_t temp_bytes, int* d_range_err, int* h_range_err, int* h_points, hipStream_t s);

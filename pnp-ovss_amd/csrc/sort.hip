@@ -3,9 +3,10 @@
 // contributor list of a lattice point must stay in ascending pixel order so that the splat adds in the order of the sequential
 // CPU algorithm (oracle/densecrf_ref.c) -- a sort that is only "a" sort changes Q in the last bit.
 //
-// Sort: 8-bit digits, one pass per digit over [begin_bit, end_bit); per pass three launches --
-//   count   : every workgroup histograms the digit of its tile of 4096 items (one LDS atomic per item) -> hist[digit][tile]
-//   scan    : exclusive prefix sum over hist in (digit, tile) order = the first output slot of each (digit, tile) run
+// Sort: 8-bit digits, one pass per digit over [begin_bit, end_bit), optionally segmented (items of a segment stay in its range:
+// the images of a batch -- the image index never goes through a pass); per pass three launches --
+//   count   : every workgroup histograms the digit of its tile of 4096 items (one LDS atomic per item) -> hist[segment][digit][tile]
+//   scan    : exclusive prefix sum over hist in (segment, digit, tile) order = the first output slot of each run
 //   scatter : the workgroup re-reads its tile in item order, ranks every item among the equal digits before it (wave: eight
 //             ballots; across the four waves and the 16 rounds of a tile: counters in LDS), lays the tile out sorted by digit in
 //             LDS and writes it out run by run -- consecutive lanes write consecutive addresses, ~16 items (128 B of keys) per run
@@ -26,6 +27,7 @@ namespace {
 
 constexpr int kSortThreads = 256, kSortRounds = 16, kSortTile = kSortThreads * kSortRounds;   // 4096 items per workgroup
 constexpr int kScanThreads = 256, kScanIpt = 32, kScanTile = kScanThreads * kScanIpt;       // 8192 items per workgroup
+constexpr int kSortMaxSegs = 64;
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -139,23 +141,45 @@ int scan_rec(const int* in, int* out, size_t n, bool inclusive, int* temp, hipSt
 }
 
 // ---- radix sort ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSortThreads) void sort_count_kernel(const uint64_t* __restrict__ keys, size_t n, int shift, int ntiles,
-                                                                  int* __restrict__ hist) {
+// Segments: items [off[s], off[s+1]) are sorted among themselves and stay where they are (the images of a batch: their
+// entries are generated image by image, so the image index never has to go through a radix pass).  Tiles do not straddle
+// segments; the histogram is laid out (segment, digit, tile of the segment), whose prefix sum IS the segmented output order.
+struct SortSegs {
+    int nseg;
+    unsigned off[kSortMaxSegs + 1];
+    int tile_off[kSortMaxSegs + 1];                 // first tile of each segment; tile_off[nseg] = all tiles
+};
+// tile `blk` -> its items [t0, t0 + tile_n) and the index of its digit-0 histogram cell / the cell stride of a digit
+__device__ __forceinline__ void sort_tile(const SortSegs& sg, int blk, unsigned& t0, int& tile_n, int& h0, int& hstride) {
+    int sgi = 0;
+    while (sgi + 1 < sg.nseg && blk >= sg.tile_off[sgi + 1]) sgi++;
+    const int tis = blk - sg.tile_off[sgi];
+    hstride = sg.tile_off[sgi + 1] - sg.tile_off[sgi];
+    h0 = 256 * sg.tile_off[sgi] + tis;
+    t0 = sg.off[sgi] + (unsigned)tis * kSortTile;
+    const unsigned left = sg.off[sgi + 1] - t0;
+    tile_n = (int)(left < (unsigned)kSortTile ? left : (unsigned)kSortTile);
+}
+
+__global__ __launch_bounds__(kSortThreads) void sort_count_kernel(const uint64_t* __restrict__ keys, const SortSegs sg, int shift,
+                                                                  int dmask, int* __restrict__ hist) {
     __shared__ int cnt[256];
     cnt[threadIdx.x] = 0;
     __syncthreads();
-    const size_t t0 = (size_t)blockIdx.x * kSortTile;
+    unsigned t0;
+    int tile_n, h0, hstride;
+    sort_tile(sg, blockIdx.x, t0, tile_n, h0, hstride);
 #pragma unroll 4
     for (int r = 0; r < kSortRounds; r++) {
-        const size_t idx = t0 + (size_t)r * kSortThreads + threadIdx.x;
-        if (idx < n) atomicAdd(&cnt[(int)((keys[idx] >> shift) & 255)], 1);
+        const int i = r * kSortThreads + threadIdx.x;
+        if (i < tile_n) atomicAdd(&cnt[(int)(keys[t0 + i] >> shift) & dmask], 1);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = cnt[threadIdx.x];       // digit-major: the scan order of the pass
+    hist[(size_t)h0 + (size_t)threadIdx.x * hstride] = cnt[threadIdx.x];       // (segment, digit, tile): the scan order of the pass
 }
 
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                                    size_t n, int shift, int ntiles, const int* __restrict__ hist_scanned,
+                                                                    const SortSegs sg, int shift, int dmask, const int* __restrict__ hist_scanned,
                                                                     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
     __shared__ uint64_t skey[kSortTile];            // 32 KB: the tile sorted by digit
     __shared__ uint32_t sval[kSortTile];            // 16 KB
@@ -164,8 +188,9 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
     __shared__ int gbase[256];                      // first output slot of this tile's run of each digit
     __shared__ int sh[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t t0 = (size_t)blockIdx.x * kSortTile;
-    const int tile_n = (int)((n - t0) < (size_t)kSortTile ? (n - t0) : (size_t)kSortTile);
+    unsigned t0;
+    int tile_n, h0, hstride;
+    sort_tile(sg, blockIdx.x, t0, tile_n, h0, hstride);
 
     // digit counts of the tile (recounted: 4096 LDS atomics are cheaper than a second global array) -> local starts
     run[tid] = 0;
@@ -180,7 +205,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
         if (i < tile_n) {
             k[r] = keys[t0 + i];
             v[r] = vals[t0 + i];
-            atomicAdd(&run[(int)((k[r] >> shift) & 255)], 1);
+            atomicAdd(&run[(int)(k[r] >> shift) & dmask], 1);
         }
     }
     __syncthreads();
@@ -188,7 +213,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
         const int c = run[tid];
         int tot;
         const int ex = block_excl_scan(c, sh, &tot);
-        gbase[tid] = hist_scanned[(size_t)tid * ntiles + blockIdx.x] - ex;       // global slot of sorted-tile slot j: gbase[d] + j
+        gbase[tid] = hist_scanned[(size_t)h0 + (size_t)tid * hstride] - ex;       // global slot of sorted-tile slot j: gbase[d] + j
         run[tid] = ex;                              // running slot of the digit: start + items placed so far
     }
 #pragma unroll
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
     for (int r = 0; r < kSortRounds; r++) {
         const int i = r * kSortThreads + tid;
         const bool on = i < tile_n;
-        const int d = on ? (int)((k[r] >> shift) & 255) : 0;
+        const int d = on ? (int)(k[r] >> shift) & dmask : 0;
         // lanes of this wave holding the same digit (inactive lanes drop out through the `on` ballot)
         uint64_t peers = __ballot(on);
 #pragma unroll
@@ -233,7 +258,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
         const int j = r * kSortThreads + tid;
         if (j < tile_n) {
             const uint64_t kk = skey[j];
-            const size_t g = (size_t)(gbase[(int)((kk >> shift) & 255)] + j);
+            const size_t g = (size_t)(gbase[(int)(kk >> shift) & dmask] + j);
             keys_out[g] = kk;
             vals_out[g] = sval[j];
         }
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
 }  // namespace
 
 size_t sort_temp_bytes(size_t n) {
-    const size_t ntiles = (n + kSortTile - 1) / kSortTile;
+    const size_t ntiles = (n + kSortTile - 1) / kSortTile + kSortMaxSegs;      // (a segmented sort rounds every segment up to a tile)
     const size_t hist = (256 * ntiles + 63) / 64 * 64;
     const size_t a = hist + scan_temp_ints(256 * ntiles);       // sort: histogram + its scan's tile sums
     const size_t b = scan_temp_ints(n);                         // a scan over n items
@@ -256,16 +281,29 @@ int device_scan_i32(const int* in, int* out, size_t n, bool inclusive, void* tem
     return scan_rec(in, out, n, inclusive, reinterpret_cast<int*>(temp), s);
 }
 
-// Sorts (keys_in, vals_in)[0, n) by the key bits [begin_bit, end_bit) and, above them, [begin2, end2) (empty when end2 <= begin2;
-// the bits between the two ranges must be equal in all keys: the Gaussian lattice's keys are 32 coordinate bits and the image
-// index at bit 55) into (keys_out, vals_out); stable; destroys the inputs.
+// Sorts (keys_in, vals_in)[0, n) by the key bits [begin_bit, end_bit) into (keys_out, vals_out); stable; destroys the inputs.
+// seg_off (host array of nseg + 1 ascending item offsets, seg_off[0] = 0, seg_off[nseg] = n; nullptr = one segment): the items
+// of a segment are sorted among themselves and stay in the segment's range.
 int radix_sort_pairs(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, uint32_t* vals_out, size_t n, int begin_bit, int end_bit,
-                     int begin2, int end2, void* temp, size_t temp_bytes, hipStream_t s) {
+                     const size_t* seg_off, int nseg, void* temp, size_t temp_bytes, hipStream_t s) {
     if (!n) return PNP_OK;
-    if (n >= ((size_t)1 << 31) || end_bit <= begin_bit || end_bit > 64 || end2 > 64 || (end2 > begin2 && begin2 < end_bit) ||
-        sort_temp_bytes(n) > temp_bytes)
-        return PNP_ERR_ARG;
-    const int ntiles = (int)((n + kSortTile - 1) / kSortTile);
+    if (n >= ((size_t)1 << 31) || end_bit <= begin_bit || end_bit > 64 || sort_temp_bytes(n) > temp_bytes) return PNP_ERR_ARG;
+    SortSegs sg;
+    if (!seg_off) nseg = 1;
+    if (nseg < 1 || nseg > kSortMaxSegs) return PNP_ERR_ARG;
+    int ntiles = 0, ns = 0;
+    for (int i = 0; i < nseg; i++) {
+        const size_t a = seg_off ? seg_off[i] : 0, b = seg_off ? seg_off[i + 1] : n;
+        if (b < a || b > n || (i == 0 && a != 0)) return PNP_ERR_ARG;
+        if (b == a) continue;                                   // empty segments own no tiles
+        sg.off[ns] = (unsigned)a;
+        sg.tile_off[ns] = ntiles;
+        ntiles += (int)((b - a + kSortTile - 1) / kSortTile);
+        sg.off[++ns] = (unsigned)b;
+    }
+    if (seg_off && seg_off[nseg] != n) return PNP_ERR_ARG;
+    sg.nseg = ns;
+    sg.tile_off[ns] = ntiles;
     const size_t nh = (size_t)256 * ntiles;
     int* hist = reinterpret_cast<int*>(temp);
     int* scan_tmp = hist + (nh + 63) / 64 * 64;
@@ -273,16 +311,13 @@ int radix_sort_pairs(uint64_t* keys_in, uint64_t* keys_out, uint32_t* vals_in, u
     uint64_t* kout = keys_out;
     uint32_t* vin = vals_in;
     uint32_t* vout = vals_out;
-    int shifts[16], np = 0;                          // a digit may reach past its range into bits that are equal in all keys
-    for (int b = begin_bit; b < end_bit; b += 8) shifts[np++] = b;
-    for (int b = begin2; b < end2; b += 8) shifts[np++] = b;
-    for (int i = 0; i < np; i++) {
-        const int shift = shifts[i];
-        hipLaunchKernelGGL(sort_count_kernel, dim3(ntiles), dim3(kSortThreads), 0, s, (const uint64_t*)kin, n, shift, ntiles, hist);
+    for (int shift = begin_bit; shift < end_bit; shift += 8) {
+        const int dmask = end_bit - shift >= 8 ? 255 : (1 << (end_bit - shift)) - 1;      // the last digit stops at end_bit
+        hipLaunchKernelGGL(sort_count_kernel, dim3(ntiles), dim3(kSortThreads), 0, s, (const uint64_t*)kin, sg, shift, dmask, hist);
         const int r = scan_rec(hist, hist, nh, false, scan_tmp, s);
         if (r != PNP_OK) return r;
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, s, (const uint64_t*)kin, (const uint32_t*)vin, n, shift,
-                           ntiles, (const int*)hist, kout, vout);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(kSortThreads), 0, s, (const uint64_t*)kin, (const uint32_t*)vin, sg, shift,
+                           dmask, (const int*)hist, kout, vout);
         uint64_t* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }

@@ -93,7 +93,7 @@ def load_library():
         "pnp_op_gemm_x3a": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, i32, vp, i32, vp]),
         "pnp_dbg_gemm_stamps": (i32, [vp, i32]),
         "pnp_op_xattn": (i32, [i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
-        "pnp_op_sort_pairs": (i32, [vp, vp, vp, vp, i64, i32, i32, vp]),
+        "pnp_op_sort_pairs": (i32, [vp, vp, vp, vp, i64, i32, i32, vp, i32, vp]),
         "pnp_op_scan_i32": (i32, [vp, vp, i64, i32, vp]),
     }
     for name, (res, args) in sig.items():

@@ -98,10 +98,50 @@ def test_lattice_sort_pairs_is_a_stable_sort(n, bits):
         order = np.argsort(sel, kind="stable")
         kin, vin = _dev(keys.view(np.int64)), _dev(vals.view(np.int32))
         kout, vout = torch.empty_like(kin), torch.empty_like(vin)
-        assert lib.pnp_op_sort_pairs(kin.data_ptr(), kout.data_ptr(), vin.data_ptr(), vout.data_ptr(), n, lo, hi, None) == 0
+        assert lib.pnp_op_sort_pairs(kin.data_ptr(), kout.data_ptr(), vin.data_ptr(), vout.data_ptr(), n, lo, hi, None, 0, None) == 0
         torch.cuda.synchronize()
         np.testing.assert_array_equal(vout.cpu().numpy().view(np.uint32), vals[order], err_msg=f"{kind} n={n} bits={bits}")
         np.testing.assert_array_equal(kout.cpu().numpy().view(np.uint64), keys[order])
+        # bits above `hi` must not take part (the lattice keys carry the image index there)
+        dirty = keys | (rng.integers(0, 4, size=n, dtype=np.uint64) << np.uint64(min(hi, 62)))
+        kin, vin = _dev(dirty.view(np.int64)), _dev(vals.view(np.int32))
+        assert lib.pnp_op_sort_pairs(kin.data_ptr(), kout.data_ptr(), vin.data_ptr(), vout.data_ptr(), n, lo, hi, None, 0, None) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(vout.cpu().numpy().view(np.uint32), vals[order], err_msg=f"{kind} n={n} bits={bits} (dirty high bits)")
+
+
+@pytest.mark.parametrize("n", [10, 5000, 123_457, 2_000_003])
+def test_lattice_sort_pairs_segmented(n):
+    """Segments (the images of a batch) are sorted among themselves and stay in place: ragged segment lengths incl. empty ones,
+    single-item ones and lengths around the 4096-item tile."""
+    import ctypes
+    lib = _lib()
+    rng = np.random.default_rng(n)
+    for nseg in (1, 2, 7, 64):
+        cuts = np.sort(rng.integers(0, n + 1, size=nseg - 1)) if nseg > 1 else np.zeros(0, dtype=np.int64)
+        if nseg >= 7:
+            cuts[1] = cuts[0]                                     # an empty segment
+        off = np.concatenate([[0], cuts, [n]]).astype(np.uint64)
+        keys = rng.integers(0, 2**40, size=n, dtype=np.uint64) & np.uint64((1 << 40) - 1)
+        keys[rng.integers(0, n, size=n // 3)] &= np.uint64(0xFF)    # ties
+        vals = np.arange(n, dtype=np.uint32)
+        ref_v = np.empty_like(vals)
+        ref_k = np.empty_like(keys)
+        for i in range(nseg):
+            a, b = int(off[i]), int(off[i + 1])
+            o = np.argsort(keys[a:b], kind="stable")
+            ref_v[a:b] = vals[a:b][o]
+            ref_k[a:b] = keys[a:b][o]
+        kin, vin = _dev(keys.view(np.int64)), _dev(vals.view(np.int32))
+        kout, vout = torch.empty_like(kin), torch.empty_like(vin)
+        h_off = (ctypes.c_size_t * (nseg + 1))(*[int(x) for x in off])
+        assert lib.pnp_op_sort_pairs(kin.data_ptr(), kout.data_ptr(), vin.data_ptr(), vout.data_ptr(), n, 0, 40, h_off, nseg, None) == 0
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(vout.cpu().numpy().view(np.uint32), ref_v, err_msg=f"n={n} nseg={nseg}")
+        np.testing.assert_array_equal(kout.cpu().numpy().view(np.uint64), ref_k)
+    bad = (ctypes.c_size_t * 3)(0, n + 1, n)
+    assert lib.pnp_op_sort_pairs(kin.data_ptr(), kout.data_ptr(), vin.data_ptr(), vout.data_ptr(), n, 0, 40, bad, 2, None) != 0
+    assert lib.pnp_op_sort_pairs(kin.data_ptr(), kout.data_ptr(), vin.data_ptr(), vout.data_ptr(), n, 0, 40, h_off, 65, None) != 0
 
 
 @pytest.mark.parametrize("n", [1, 31, 8192, 8193, 100_003, 70_000_000])
@@ -123,8 +163,8 @@ def test_lattice_scan_i32(n, inclusive):
             ref = ref - a
         np.testing.assert_array_equal(d_out.cpu().numpy().astype(np.int64), ref)
     assert lib.pnp_op_scan_i32(None, None, 0, 1, None) == 0
-    assert lib.pnp_op_sort_pairs(None, None, None, None, 0, 0, 8, None) == 0
-    assert lib.pnp_op_sort_pairs(None, None, None, None, 5, 0, 8, None) != 0
+    assert lib.pnp_op_sort_pairs(None, None, None, None, 0, 0, 8, None, 0, None) == 0
+    assert lib.pnp_op_sort_pairs(None, None, None, None, 5, 0, 8, None, 0, None) != 0
 
 
 
