@@ -23,8 +23,6 @@
 
 namespace pnp {
 
-namespace {
-
 constexpr int kSortThreads = 256, kSortRounds = 16, kSortTile = kSortThreads * kSortRounds;   // 4096 items per workgroup
 constexpr int kScanThreads = 256, kScanIpt = 32, kScanTile = kScanThreads * kScanIpt;       // 8192 items per workgroup
 constexpr int kSortMaxSegs = 64;
@@ -114,7 +112,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_tile_kernel(const int* __re
     }
 }
 
-size_t scan_temp_ints(size_t n) {                   // tile sums of every level
+static size_t scan_temp_ints(size_t n) {                   // tile sums of every level
     size_t tot = 0;
     while (n > (size_t)kScanTile) {
         n = (n + kScanTile - 1) / kScanTile;
@@ -123,7 +121,7 @@ size_t scan_temp_ints(size_t n) {                   // tile sums of every level
     return tot;
 }
 
-int scan_rec(const int* in, int* out, size_t n, bool inclusive, int* temp, hipStream_t s) {
+static int scan_rec(const int* in, int* out, size_t n, bool inclusive, int* temp, hipStream_t s) {
     const int al = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     if (n <= (size_t)kScanTile) {
         if (inclusive) hipLaunchKernelGGL((scan_tile_kernel<true>), dim3(1), dim3(kScanThreads), 0, s, in, n, (const int*)nullptr, out, al);
@@ -264,8 +262,6 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
         }
     }
 }
-
-}  // namespace
 
 size_t sort_temp_bytes(size_t n) {
     const size_t ntiles = (n + kSortTile - 1) / kSortTile + kSortMaxSegs;      // (a segmented sort rounds every segment up to a tile)
