@@ -418,6 +418,10 @@ __global__ __launch_bounds__(512) void vit_attn32_kernel(const bf16* __restrict_
 // DEV diagnostics: per-(wave, key tile) issue-time clock stamps of workgroup (0, 0, 0) of the split-bf16 attention
 // (tools/attn_x3_probe.py --stamps): [wave][tile][6] = loop top, barrier passed, DMA issued, S issued, softmax done, P.V issued
 __device__ unsigned long long* g_attn_stamps = nullptr;
+__device__ int g_attn_ablate = 0;
+extern "C" int pnp_dev_attn_ablate(int on) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_ablate), &on, sizeof(on)) == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
 extern "C" int pnp_dev_attn_stamps(unsigned long long* d_buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &d_buf, sizeof(d_buf)) == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
@@ -484,6 +488,9 @@ __global__ __launch_bounds__(768) void vit_attn32_x3_kernel(const bf16* __restri
             const uint64_t d = (m_v & m_lo & d_vlo) | (m_v & ~m_lo & d_v) | (~m_v & m_lo & d_klo);
             const uint32_t ld2 = ((uint32_t)ld_qk + ((uint32_t)m_v & (uint32_t)(ld_vt - ld_qk))) * 2u;
             int rs = t * 64 + (p & 7) * 8;
+#ifdef PNP_DEV
+            if (g_attn_ablate) rs = (p & 7) * 8;          // timing-only (results garbage): every tile fetches the first one's rows (cache-hot)
+#endif
             rs = rs < N - 1 ? rs : N - 1;
             const char* const sbase = reinterpret_cast<const char*>(k0 + d + (uint64_t)((uint32_t)rs * ld2));
             int lr = rs + prow;

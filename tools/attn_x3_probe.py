@@ -17,6 +17,8 @@ if "--dev" in sys.argv:
 if "--lib" in sys.argv:                                     # a named library variant next to the product one (A/B runs)
     hip.LIB_PATH = os.path.join(os.path.dirname(hip.LIB_PATH), sys.argv[sys.argv.index("--lib") + 1])
 lib = hip.load_library()
+if "--ablate-fetch" in sys.argv:                            # DEV library: every key tile fetches tile 0's rows (cache-hot; results garbage)
+    assert lib.pnp_dev_attn_ablate(1) == 0
 PAD = int(sys.argv[sys.argv.index("--pad") + 1]) if "--pad" in sys.argv else 64   # the engine's q|k|v row stride is 3D + 64
 
 
