@@ -7,9 +7,10 @@
 // the images of a batch -- the image index never goes through a pass); per pass three launches --
 //   count   : every workgroup histograms the digit of its tile of 4096 items (one LDS atomic per item) -> hist[segment][digit][tile]
 //   scan    : exclusive prefix sum over hist in (segment, digit, tile) order = the first output slot of each run
-//   scatter : the workgroup re-reads its tile in item order, ranks every item among the equal digits before it (wave: eight
-//             ballots; across the four waves and the 16 rounds of a tile: counters in LDS), lays the tile out sorted by digit in
-//             LDS and writes it out run by run -- consecutive lanes write consecutive addresses, ~16 items (128 B of keys) per run
+//   scatter : the workgroup re-reads its tile; every wave ranks a contiguous quarter of it, 64 items per round, among the equal
+//             digits before them (eight ballots; the wave's running digit counts in LDS -- no workgroup barrier inside the 16
+//             rounds), the wave totals give every wave its first slot per digit, the tile is laid out sorted by digit in LDS and
+//             written out run by run -- consecutive lanes write consecutive addresses, ~16 items (128 B of keys) per run
 // HBM traffic per pass and item: keys read twice, value read once, both written once (36 B); 24 M entries x 8 passes ~ 7 GB.
 // The passes ping-pong between the caller's input and output arrays (the input is destroyed); an even pass count ends with
 // one copy.
@@ -161,19 +162,28 @@ __device__ __forceinline__ void sort_tile(const SortSegs& sg, int blk, unsigned&
 
 __global__ __launch_bounds__(kSortThreads) void sort_count_kernel(const uint64_t* __restrict__ keys, const SortSegs sg, int shift,
                                                                   int dmask, int* __restrict__ hist) {
-    __shared__ int cnt[256];
-    cnt[threadIdx.x] = 0;
+    __shared__ int cnt[4][256];                     // one histogram per wave (a quarter of the atomic traffic per address)
+#pragma unroll
+    for (int w = 0; w < 4; w++) cnt[w][threadIdx.x] = 0;
     __syncthreads();
     unsigned t0;
     int tile_n, h0, hstride;
     sort_tile(sg, blockIdx.x, t0, tile_n, h0, hstride);
-#pragma unroll 4
+    int* const mine = cnt[threadIdx.x >> 6];
+    uint64_t k[kSortRounds];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; r++) {         // all loads first, then the atomics
+        const int i = r * kSortThreads + threadIdx.x;
+        k[r] = i < tile_n ? keys[t0 + i] : 0;
+    }
+#pragma unroll
     for (int r = 0; r < kSortRounds; r++) {
         const int i = r * kSortThreads + threadIdx.x;
-        if (i < tile_n) atomicAdd(&cnt[(int)(keys[t0 + i] >> shift) & dmask], 1);
+        if (i < tile_n) atomicAdd(&mine[(int)(k[r] >> shift) & dmask], 1);
     }
     __syncthreads();
-    hist[(size_t)h0 + (size_t)threadIdx.x * hstride] = cnt[threadIdx.x];       // (segment, digit, tile): the scan order of the pass
+    hist[(size_t)h0 + (size_t)threadIdx.x * hstride] =
+        cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];       // (segment, digit, tile): the scan order of the pass
 }
 
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
@@ -181,76 +191,77 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint64
                                                                     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
     __shared__ uint64_t skey[kSortTile];            // 32 KB: the tile sorted by digit
     __shared__ uint32_t sval[kSortTile];            // 16 KB
-    __shared__ int wcnt[4][256];                    // items of each digit per wave, this round
-    __shared__ int run[256];                        // items of each digit in the rounds before this one
-    __shared__ int gbase[256];                      // first output slot of this tile's run of each digit
+    __shared__ int wrun[4][256];                    // per wave: items of each digit seen so far (after the ranking pass: the wave's totals,
+                                                    // then the wave's first slot of each digit in the sorted tile)
+    __shared__ int gbase[256];                      // output slot of the sorted tile's slot j of digit d: gbase[d] + j
     __shared__ int sh[4];
+    constexpr int kWaveItems = kSortTile / 4;       // a wave ranks a CONTIGUOUS quarter of the tile, 64 items per round: item order =
+                                                    // (wave, round, lane), so the four waves rank without a workgroup barrier per round
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned t0;
     int tile_n, h0, hstride;
     sort_tile(sg, blockIdx.x, t0, tile_n, h0, hstride);
-
-    // digit counts of the tile (recounted: 4096 LDS atomics are cheaper than a second global array) -> local starts
-    run[tid] = 0;
-    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) wrun[w][tid] = 0;
     uint64_t k[kSortRounds];
     uint32_t v[kSortRounds];
 #pragma unroll
     for (int r = 0; r < kSortRounds; r++) {
-        const int i = r * kSortThreads + tid;
+        const int i = wave * kWaveItems + r * 64 + lane;
         k[r] = 0;
         v[r] = 0;
         if (i < tile_n) {
             k[r] = keys[t0 + i];
             v[r] = vals[t0 + i];
-            atomicAdd(&run[(int)(k[r] >> shift) & dmask], 1);
         }
     }
     __syncthreads();
-    {
-        const int c = run[tid];
-        int tot;
-        const int ex = block_excl_scan(c, sh, &tot);
-        gbase[tid] = hist_scanned[(size_t)h0 + (size_t)tid * hstride] - ex;       // global slot of sorted-tile slot j: gbase[d] + j
-        run[tid] = ex;                              // running slot of the digit: start + items placed so far
-    }
-#pragma unroll
-    for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
-    __syncthreads();
 
+    // ranking pass: rank[r] = items of the same digit before this one IN THE WAVE's quarter
+    int rank[kSortRounds];
+    int* const myrun = wrun[wave];
     const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
 #pragma unroll
     for (int r = 0; r < kSortRounds; r++) {
-        const int i = r * kSortThreads + tid;
+        const int i = wave * kWaveItems + r * 64 + lane;
         const bool on = i < tile_n;
         const int d = on ? (int)(k[r] >> shift) & dmask : 0;
-        // lanes of this wave holding the same digit (inactive lanes drop out through the `on` ballot)
-        uint64_t peers = __ballot(on);
+        uint64_t peers = __ballot(on);              // lanes of this wave holding the same digit
 #pragma unroll
         for (int b = 0; b < 8; b++) {
             const uint64_t m = __ballot((d >> b) & 1);
             peers &= ((d >> b) & 1) ? m : ~m;
         }
         const int before = __popcll(peers & lt);
-        if (on && before == 0) wcnt[wave][d] = __popcll(peers);                  // the group's first lane
-        __syncthreads();
-        if (on) {
-            int slot = run[d] + before;
+        const int seen = myrun[d];                  // the wave's LDS accesses complete in program order: read, then the leaders' update
+        rank[r] = seen + before;
+        __builtin_amdgcn_wave_barrier();
+        if (on && before == 0) myrun[d] = seen + __popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {   // thread d: totals of digit d -> first slot of the digit in the sorted tile, of each wave's run inside it, and in the output
+        const int c0 = wrun[0][tid], c1 = wrun[1][tid], c2 = wrun[2][tid], c3 = wrun[3][tid];
+        int tot;
+        const int ex = block_excl_scan(c0 + c1 + c2 + c3, sh, &tot);
+        wrun[0][tid] = ex;
+        wrun[1][tid] = ex + c0;
+        wrun[2][tid] = ex + c0 + c1;
+        wrun[3][tid] = ex + c0 + c1 + c2;
+        gbase[tid] = hist_scanned[(size_t)h0 + (size_t)tid * hstride] - ex;
+    }
+    __syncthreads();
 #pragma unroll
-            for (int w = 0; w < 3; w++)
-                if (w < wave) slot += wcnt[w][d];
+    for (int r = 0; r < kSortRounds; r++) {
+        const int i = wave * kWaveItems + r * 64 + lane;
+        if (i < tile_n) {
+            const int slot = myrun[(int)(k[r] >> shift) & dmask] + rank[r];
             skey[slot] = k[r];
             sval[slot] = v[r];
         }
-        __syncthreads();
-        {   // thread d closes the round for digit d
-            run[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-#pragma unroll
-            for (int w = 0; w < 4; w++) wcnt[w][tid] = 0;
-        }
-        __syncthreads();
     }
-    // the sorted tile leaves run by run: slot j belongs to digit (key >> shift) & 255, its output slot is gbase[digit] + j
+    __syncthreads();
+    // the sorted tile leaves run by run: slot j belongs to digit (key >> shift) & dmask, its output slot is gbase[digit] + j
 #pragma unroll 4
     for (int r = 0; r < kSortRounds; r++) {
         const int j = r * kSortThreads + tid;
