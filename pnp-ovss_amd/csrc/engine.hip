@@ -1492,6 +1492,8 @@ extern "C" int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, siz
         if (n == "crf_idbase_bilateral") return set(p.lat[1].idbase, ((size_t)p.maxB + 1) * 4);
         if (n == "crf_norm_gauss") return set(p.norm[0], (size_t)p.max_total_pix * 4);
         if (n == "crf_norm_bilateral") return set(p.norm[1], (size_t)p.max_total_pix * 4);
+        if (n == "crf_offset_gauss") return set(p.lat[0].offset, (size_t)p.max_total_pix * 3 * 4);          // per pixel: 3 lattice ids
+        if (n == "crf_offset_bilateral") return set(p.lat[1].offset, (size_t)p.max_total_pix * 6 * 4);  // per pixel: 6 lattice ids
         if (n == "crf_nbr8_gauss") return set(p.lat[0].nbr8, (size_t)(p.lat[0].D1 / 2) * p.lat[0].cap * sizeof(CrfNbr8));
         if (n == "crf_nbr8_bilateral") return set(p.lat[1].nbr8, (size_t)(p.lat[1].D1 / 2) * p.lat[1].cap * sizeof(CrfNbr8));
     }
