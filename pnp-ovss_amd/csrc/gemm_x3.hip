@@ -35,6 +35,13 @@
 #include "gemm.h"
 #include "gemm_wide.h"
 
+// epilogue stores: -DPNP_EPI_NT builds mark them non-temporal (A/B experiment: do the output tiles evict the operand panels from L2?)
+#ifdef PNP_EPI_NT
+#define PNP_EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define PNP_EPI_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace pnp {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t frag16;      // one lane's 8 bf16 of a 16x16x32 operand
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int it = 0; it < 16; it++) {
                         const int m = em0 + wm * 128 + half * 64 + it * 4 + (lane >> 4);
-                        if (full || (m < g.M && nv)) *reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t) = sv[it];
+                        if (full || (m < g.M && nv)) PNP_EPI_STORE(reinterpret_cast<bf16x4*>(obase + (size_t)(half * 64 + it * 4) * g.ldo_t), sv[it]);
                     }
                 }
             }
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
                     f32x4 v = sv[it] + bv;
                     if constexpr (kResid) v += rcur[it];
                     const int m = em0 + wm * 128 + qd * 32 + it * 4 + (lane >> 4);
-                    if (full || (m < g.M && nv)) *reinterpret_cast<f32x4*>(obase + (size_t)(qd * 32 + it * 4) * g.ldo) = v;
+                    if (full || (m < g.M && nv)) PNP_EPI_STORE(reinterpret_cast<f32x4*>(obase + (size_t)(qd * 32 + it * 4) * g.ldo), v);
                 }
                 if (qd == 0) request_next();
             }
