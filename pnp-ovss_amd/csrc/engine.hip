@@ -78,6 +78,7 @@ struct pnp_engine {
 
     // ---- activations
     int ldq = 0;               // row stride (elements) of the fused q|k|v buffer
+    float* x0 = nullptr;       // [M, D] token embeddings of drop iteration 0 (patch embed + pos, cls row): later iterations reuse them
     void *patches = nullptr, *xn = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *h1 = nullptr, *embT = nullptr;
     float *x = nullptr, *emb32 = nullptr;
     void *Knat = nullptr, *Vnat = nullptr, *Kt = nullptr, *Vt = nullptr;
@@ -241,6 +242,29 @@ __global__ void tok_to_feat_kernel(const float* __restrict__ src, int ld_src, fl
 
 // fp32 [rows, cols] staging -> compute-type device weight (optionally transposed); split: a bf16 (hi | lo) pair in
 // the same bytes as the fp32 copy, hi first (split-bf16 mode, weights of the wide GEMMs)
+// Patch embeddings of a later drop iteration: the images are the ones of iteration 0 with more 16 x 16 blocks zeroed
+// (PnP.py:597-603), so a token's embedding is either what iteration 0 computed or, for a dropped patch, bias + pos exactly as the
+// GEMM epilogue forms it from a zero accumulator ((0 + bias[n]) + pos[t][n]); the cls row never changes.  One pass over x instead of
+// patchify + the patch GEMM.
+__global__ void embed_reuse_kernel(const float* __restrict__ x0, const uint8_t* __restrict__ dropped, const float* __restrict__ bias,
+                                   const float* __restrict__ pos, float* __restrict__ x, int rows, int N, int D4) {
+    const size_t total = (size_t)rows * D4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / D4), c = (int)(i - (size_t)m * D4);
+        const int b = m / N, t = m - b * N;
+        f32x4 v;
+        if (t > 0 && dropped[(size_t)b * (N - 1) + (t - 1)]) {
+            const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[c];
+            const f32x4 pv = reinterpret_cast<const f32x4*>(pos)[(size_t)t * D4 + c];
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = __fadd_rn(__fadd_rn(0.0f, bv[e]), pv[e]);
+        } else {
+            v = reinterpret_cast<const f32x4*>(x0)[i];
+        }
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    }
+}
+
 int make_weight(pnp_engine* e, const float* src32, int rows, int cols, bool transpose, void** out, bool split = false) {
     KCHK(e, dalloc_t(e, out, (size_t)rows * cols));
     const float* s = src32;
@@ -366,6 +390,7 @@ extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
     // activations
     KCHK(e, dalloc_t(e, &e->patches, B * e->PP * 768));
     KCHK(e, dalloc(e, &e->x, M * D));
+    KCHK(e, dalloc(e, &e->x0, M * D));
     KCHK(e, dalloc_t(e, &e->xn, M * D));
     // bf16 / split-bf16 modes: fused q|k|v rows at a stride of 3D + 64 elements; fp32 mode: q|k rows (v goes to vt).
     // The pad matters: an attention K / V tile is 64 rows x 128 B at the row stride, and at 6144 B (3D bf16, D = 1024) those
@@ -675,19 +700,32 @@ extern "C" int pnp_finalize_weights(pnp_engine* e) {
 
 // =========================================================================================== model
 
+// embed: 0 = compute the token embeddings (the operator form) | 1 = compute them and keep a copy (drop iteration 0) | 2 = the
+// images are those of the last embed-1 call with the patches of d_dropped zeroed: reuse the copy (embed_reuse_kernel)
+static int vit_forward_impl(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream, int embed);
 extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream) {
+    return vit_forward_impl(e, d_images, d_dropped, B, stream, 0);
+}
+static int vit_forward_impl(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream, int embed) {
     if (!e || !d_images) return PNP_ERR_ARG;
     if (!e->finalized) return fail(e, PNP_ERR_STATE, "weights not finalized");
     if (B <= 0 || B > e->c.max_batch) return fail(e, PNP_ERR_ARG, "batch %d out of range (max %d)", B, e->c.max_batch);
     hipStream_t s = (hipStream_t)stream;
     const int D = e->D, N = e->N, M = B * N, F = D * e->c.vit_mlp_ratio, bf = e->bf;
     const int ldv = e->c.max_batch * e->Npad;
+    if (embed == 2 && d_dropped) {
+        hipLaunchKernelGGL(embed_reuse_kernel, dim3(2048), dim3(256), 0, s, (const float*)e->x0, d_dropped, (const float*)e->patch_b,
+                           (const float*)e->pos, e->x, M, N, D / 4);
+        if (hipGetLastError() != hipSuccess) return fail(e, PNP_ERR_HIP, "embed_reuse launch");
+    } else {
     KCHK(e, patchify(bf, d_images, d_dropped, e->patches, B, e->c.img_size, e->P, s));
     KCHK(e, cls_rows(e->cls, e->pos, e->x, B, N, D, s));
     {
         GemmArgs g = G_(e->patches, 768, e->patch_w, 768, B * e->PP, D, 768);
         g.bias = e->patch_b; g.resid = e->pos; g.ldr = D; g.out_f32 = e->x; g.ldo = D; g.row_div = e->PP;
         KCHK(e, egemm(e, bf, g, s));
+    }
+    if (embed == 1) HIPCHK(e, hipMemcpyAsync(e->x0, e->x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     const float scale = 1.0f / sqrtf(64.f);
     if (e->x3) {
@@ -841,8 +879,16 @@ extern "C" int pnp_cross_kv(pnp_engine* e, int32_t B, void* stream) {
     return PNP_OK;
 }
 
+// reuse_prefix: the token ids / mask are those of the previous call on this engine (drop iterations 1..): the embeddings and the
+// self-attention sub-layer of text layer 0 do not see the image -- their activations of the previous call are still in place
+static int text_forward_impl(pnp_engine* e, const int64_t* d_ids, const int64_t* d_mask, int32_t ld, int32_t B, int32_t L,
+                             float* d_logits, void* stream, bool reuse_prefix);
 extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const int64_t* d_mask, int32_t ld, int32_t B,
                                       int32_t L, float* d_logits, void* stream) {
+    return text_forward_impl(e, d_ids, d_mask, ld, B, L, d_logits, stream, false);
+}
+static int text_forward_impl(pnp_engine* e, const int64_t* d_ids, const int64_t* d_mask, int32_t ld, int32_t B, int32_t L,
+                             float* d_logits, void* stream, bool reuse_prefix) {
     if (!e || !d_ids || !d_mask) return PNP_ERR_ARG;
     if (!e->finalized) return fail(e, PNP_ERR_STATE, "weights not finalized");
     if (B <= 0 || B > e->c.max_batch || L < 5 || L > e->c.max_text_len || ld < L)
@@ -851,14 +897,17 @@ extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const
     const int H = e->H, I = e->I, TL = e->TL, R = B * L, bf = e->bf, N = e->N, D = e->D;
     const int ldv = e->c.max_batch * e->Npad;
     (void)D;
-    KCHK(e, text_embed(d_ids, ld, e->word, e->tpos, e->temb, B, L, H, e->c.enc_token_id, e->c.vocab, s));
-    KCHK(e, layernorm(bf, e->temb, e->eln_w, e->eln_b, e->c.txt_ln_eps, R, H, e->h0, e->h0T, nullptr, nullptr, s));
+    if (!reuse_prefix) {
+        KCHK(e, text_embed(d_ids, ld, e->word, e->tpos, e->temb, B, L, H, e->c.enc_token_id, e->c.vocab, s));
+        KCHK(e, layernorm(bf, e->temb, e->eln_w, e->eln_b, e->c.txt_ln_eps, R, H, e->h0, e->h0T, nullptr, nullptr, s));
+    }
     const float* h = e->h0;
     const void* hT = e->h0T;
     for (int i = 0; i < TL; i++) {
         const TextLayerW& w = e->txt[i];
         TextLayerA& a = e->ta[i];
         const bool stash = i >= e->SL;
+        if (!(reuse_prefix && i == 0)) {
         {
             GemmArgs g = G_(hT, H, w.qkv_w, H, R, 3 * H, H);
             g.bias = w.qkv_b; g.out_t = a.qkv; g.ldo_t = 3 * H;
@@ -871,6 +920,7 @@ extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const
             KCHK(e, tgemm(e, g, s));
         }
         KCHK(e, layernorm(bf, e->tmp, w.sln_w, w.sln_b, e->c.txt_ln_eps, R, H, a.a_out, a.a_outT, a.a_hat, a.a_rstd, s));
+        }
         {
             GemmArgs g = G_(a.a_outT, H, w.cq_w, H, R, H, H);
             g.bias = w.cq_b; g.out_t = a.qc; g.ldo_t = H;
@@ -977,12 +1027,22 @@ extern "C" int pnp_gradcam_gather(pnp_engine* e, const int64_t* d_mask, int32_t 
     return PNP_OK;
 }
 
+static int compute_gradcam_impl(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
+                                const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t layer, int32_t head,
+                                float* d_out, float* d_logits, void* stream, int embed);
 extern "C" int pnp_compute_gradcam_layer(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
                                          const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t layer, int32_t head,
                                          float* d_out, float* d_logits, void* stream) {
-    int r = pnp_vit_forward(e, d_images, d_dropped, B, stream);
+    return compute_gradcam_impl(e, d_images, d_dropped, d_ids, d_mask, ld, B, L, layer, head, d_out, d_logits, stream, 0);
+}
+static int compute_gradcam_impl(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, const int64_t* d_ids,
+                                const int64_t* d_mask, int32_t ld, int32_t B, int32_t L, int32_t layer, int32_t head,
+                                float* d_out, float* d_logits, void* stream, int embed) {
+    int r = vit_forward_impl(e, d_images, d_dropped, B, stream, embed);
     if (r) return r;
-    r = pnp_text_forward_xattn(e, d_ids, d_mask, ld, B, L, d_logits, stream);
+    // drop iterations 1..: same captions as iteration 0 (embed == 2 only comes from the drop loop; a stash layer of 0 keeps the
+    // probabilities of layer 0's self-attention, which are in place as well)
+    r = text_forward_impl(e, d_ids, d_mask, ld, B, L, d_logits, stream, embed == 2);
     if (r) return r;
     r = pnp_xattn_grad_layer(e, B, L, layer, stream);
     if (r) return r;
@@ -1022,7 +1082,8 @@ extern "C" int pnp_drop_loop_layer(pnp_engine* e, const float* d_images, const i
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(e, hipMemsetAsync(e->dropped, 0, (size_t)B * e->PP, s));
     for (int it = 0; it < drop_iter; it++) {
-        int r = pnp_compute_gradcam_layer(e, d_images, e->dropped, d_ids, d_mask, ld, B, L, layer, head, e->G, d_logits, stream);
+        // the token embeddings of iteration 0 serve the later iterations (same images, more patches zeroed)
+        int r = compute_gradcam_impl(e, d_images, e->dropped, d_ids, d_mask, ld, B, L, layer, head, e->G, d_logits, stream, it == 0 ? 1 : 2);
         if (r) return r;
         r = pnp_drop_step(e, e->G, d_g0, d_agg, e->dropped, d_picks, it, B, L - 1, npick, drop_iter * npick, stream);
         if (r) return r;

@@ -1158,6 +1158,35 @@ def test_bf16_vs_f32_divergence_is_bounded():
     assert same >= 1
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16", "bf16x3"])
+def test_drop_loop_embedding_reuse_is_bit_identical(mode):
+    """pnp_drop_loop keeps the token embeddings of iteration 0 and, in the later iterations, replaces only the rows of dropped
+    patches by bias + pos (engine.hip: embed_reuse_kernel) instead of re-running patchify + the patch GEMM on the re-zeroed images
+    (PnP.py:597-603).  Against a hand-written loop of the operator-level calls, which compute the embeddings from the images
+    every time: gradcam_0, the aggregate, the picks and the logits are bit-identical."""
+    g = _golden("droploop_small.npz")
+    cfg = _cfg(g)
+    _, imgs = synth.synth_images(3, cfg.img_size, seed=int(g["image_seed"]))
+    e = _engine(cfg, int(g["weight_seed"]), mode)
+    ids, mask = _dev(g["input_ids"]), _dev(g["attention_mask"])
+    L = int(g["attention_mask"].sum(1).max())
+    d_img = _dev(imgs)
+    g0, agg, picks, logits = e.drop_loop(d_img, ids, mask, L, 9, 4)
+    torch.cuda.synchronize()
+    B, PP = 3, e.grid * e.grid
+    dropped = torch.zeros(B, PP, dtype=torch.uint8, device="cuda")
+    g0m = torch.empty_like(g0)
+    aggm = torch.empty_like(agg)
+    picksm = torch.full_like(picks, -1)
+    for it in range(4):
+        gc, lg = e.compute_gradcam(d_img, ids, mask, L, 9, dropped=dropped)
+        e.drop_step(gc, g0m, aggm, dropped, picksm, it)
+    torch.cuda.synchronize()
+    assert torch.equal(picks, picksm)
+    assert torch.equal(g0, g0m) and torch.equal(agg, aggm) and torch.equal(logits, lg)
+    assert int(dropped.sum()) == B * 40
+
+
 @pytest.mark.parametrize("mode", ["f32", "bf16x3"])
 def test_drop_loop_large_vs_reference_golden(mode):
     """The drop loop at FULL model size against the reference's own Inference_BLIP_filteredcaption run (PnP.py:564-722;
