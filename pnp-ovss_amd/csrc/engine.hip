@@ -321,8 +321,8 @@ extern "C" size_t pnp_workspace_bytes(const pnp_config* c) {
     const size_t M = B * N, R = B * L;
     size_t w = (size_t)c->vit_depth * (12 * D * D) * es + TL * (4 * H * H + 2 * H * D + 2 * H * I) * es * 2 +
                ((size_t)c->vocab + c->max_pos) * H * 4;
-    size_t a = M * (768 + D * 2 + 3 * D + D + 4 * D) * es + M * D * 8 + D * B * Npad * es + M * TL * H * es * 2 +
-               2 * TL * H * B * Npad * es;
+    size_t a = M * (768 + D * 2 + 3 * D + 64 + D + 4 * D) * es + M * D * 12 + D * B * Npad * es + M * TL * H * es * 2 +
+               2 * TL * H * B * Npad * es;            // (incl. the padded q|k|v rows and the drop loop's copy of the token embeddings)
     size_t t = TL * (R * (3 * H + 2 * H) * es + R * (H * 8 + I) * 4 + B * (H / 64) * L * (L + Npad) * 4) + R * I * (4 + es) * 2 +
                R * H * 64;
     return w + a + t + (64u << 20);
