@@ -539,7 +539,9 @@ static int xattn_launch(const void* a1, int ld1, const void* a2t, int ld2, int N
     const int nkt = (N + 15) / 16;
     if (nkt <= 4 * 8) {
         dim3 grid(nheads, B, (L + 31) / 32);
-        hipLaunchKernelGGL((xattn_kernel<T, MODE, 4, 8, 2>), grid, dim3(256), 0, s, (const T*)a1, ld1, (const T*)a2t, ld2,
+        // 8 waves of 4 key tiles (442 keys: 28 tiles): 38.7 -> 35.1 us per forward launch against 4 waves of 8 tiles -- twice the
+        // K / V rows requested at a time per CU; 16 waves of 2 tiles: 48 us
+        hipLaunchKernelGGL((xattn_kernel<T, MODE, 8, 4, 2>), grid, dim3(512), 0, s, (const T*)a1, ld1, (const T*)a2t, ld2,
                            Npad, (const T*)x, ldx, (T*)out, ldo, pbuf, Nst, L, N, nheads);
     } else if (nkt <= 16 * 10) {
         dim3 grid(nheads, B, (L + 15) / 16);
