@@ -15,7 +15,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def short(name):
-    return name.replace("pnp::", "").split("(")[0][:80]
+    return name.replace("(anonymous namespace)::", "").replace("pnp::", "").split("(")[0][:80]
 
 
 def kernel_stats(sub, out):
