@@ -545,15 +545,38 @@ __global__ __launch_bounds__(256) void unary_kernel(const float* __restrict__ ma
         const int np = (n - p0) < 256 ? (n - p0) : 256;
         if (tid < np) {
             const int i = p0 + tid;
-            float mx = m[i];
-            for (int k = 1; k < K; k++) {
-                const float v = m[(size_t)k * n + i];
+            const float* mi = m + i;
+            // channel planes in batches of eight loads in flight (a per-channel loop waits for every load in turn: 21 + 21
+            // dependent round trips per pixel); maxima and sums stay the sequential per-pixel ones
+            float mx = mi[0];
+            int k = 1;
+            for (; k + 8 <= K; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = mi[(size_t)(k + u) * n];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (v[u] > mx || v[u] != v[u]) mx = v[u];
+            }
+            for (; k < K; k++) {
+                const float v = mi[(size_t)k * n];
                 if (v > mx || v != v) mx = v;
             }
             float s = 0.f;
             float* row = utile + tid * ldt;
-            for (int k = 0; k < K; k++) {                              // the exponentials are parked in the tile: one exp per
-                const float e = pnp_expf(__fsub_rn(m[(size_t)k * n + i], mx));   // element instead of two (same values)
+            for (k = 0; k + 8 <= K; k += 8) {                            // the exponentials are parked in the tile: one exp per
+                float v[8];                                             // element instead of two (same values)
+#pragma unroll
+                for (int u = 0; u < 8; u++) v[u] = mi[(size_t)(k + u) * n];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const float e = pnp_expf(__fsub_rn(v[u], mx));
+                    row[k + u] = e;
+                    s = __fadd_rn(s, e);
+                }
+            }
+            for (; k < K; k++) {
+                const float e = pnp_expf(__fsub_rn(mi[(size_t)k * n], mx));
                 row[k] = e;
                 s = __fadd_rn(s, e);
             }
