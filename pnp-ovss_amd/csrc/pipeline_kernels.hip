@@ -281,7 +281,18 @@ __global__ void background_kernel(float* __restrict__ maps, const PostDesc* __re
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         float mx = m[(size_t)n + i];
         bool nan = mx != mx;
-        for (int c = 1; c < d.C; c++) {
+        int c = 1;
+        for (; c + 8 <= d.C; c += 8) {                       // eight channel planes in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = m[(size_t)(1 + c + u) * n + i];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                nan |= (v[u] != v[u]);
+                mx = fmaxf(mx, v[u]);
+            }
+        }
+        for (; c < d.C; c++) {
             const float v = m[(size_t)(1 + c) * n + i];
             nan |= (v != v);
             mx = fmaxf(mx, v);
@@ -732,8 +743,12 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ l
     const PostDesc d = desc[b];
     const int n = d.H * d.W, nb = n_class * n_class;
     const bool use_lds = nb <= 8192;
+    // one copy of the bins per wave while they fit (21 classes: 441 bins x 4): the pixels of an image hit a handful of
+    // (truth, prediction) pairs, and LDS atomics on one address serialise
+    const int copies = nb * 4 <= 8192 ? 4 : nb * 2 <= 8192 ? 2 : 1;
+    unsigned int* const mybins = bins + ((threadIdx.x >> 6) % copies) * nb;
     if (use_lds) {
-        for (int i = threadIdx.x; i < nb; i += 256) bins[i] = 0;
+        for (int i = threadIdx.x; i < nb * copies; i += 256) bins[i] = 0;
         __syncthreads();
     }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -741,15 +756,18 @@ __global__ __launch_bounds__(256) void hist_kernel(const uint8_t* __restrict__ l
         if (g >= 0.f && g < (float)n_class) {
             const int gi = (int)g, pi = labels[label_off[b] + i];
             if (pi < n_class) {
-                if (use_lds) atomicAdd(&bins[gi * n_class + pi], 1u);
+                if (use_lds) atomicAdd(&mybins[gi * n_class + pi], 1u);
                 else atomicAdd(&hist[(size_t)gi * n_class + pi], 1ULL);
             }
         }
     }
     if (use_lds) {
         __syncthreads();
-        for (int i = threadIdx.x; i < nb; i += 256)
-            if (bins[i]) atomicAdd(&hist[i], (unsigned long long)bins[i]);
+        for (int i = threadIdx.x; i < nb; i += 256) {
+            unsigned int t = bins[i];
+            for (int c = 1; c < copies; c++) t += bins[c * nb + i];
+            if (t) atomicAdd(&hist[i], (unsigned long long)t);
+        }
     }
 }
 
@@ -868,7 +886,10 @@ int argmax_remap(const float* q, const PostDesc* desc, const int32_t* lut, int l
 
 int confusion_hist(const uint8_t* labels, const float* gt, const PostDesc* desc, const size_t* label_off,
                    unsigned long long* hist, int n_class, int B, int maxHW, hipStream_t s) {
-    const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
+    // bins in LDS (n_class^2 <= 8192): every workgroup pays for zeroing and flushing its bins, so few, long-running workgroups
+    // per image (32 x 3500 pixels at 336^2, not 441 x 256: 181 us per launch was that overhead); global-atomic form: as before
+    const int cap = n_class * n_class <= 8192 ? 32 : 256;
+    const int nb = (maxHW + 255) / 256 < cap ? (maxHW + 255) / 256 : cap;
     hipLaunchKernelGGL(hist_kernel, dim3(nb, B), dim3(256), 0, s, labels, gt, desc, label_off, hist, n_class);
     return ok();
 }
