@@ -236,8 +236,10 @@ int pnp_jpeg_decode(const uint8_t* d_data, const pnp_jpeg_image* d_images, const
  * "crf_q", "P", "dP", "crf_M" (int32 [2][B+1] lattice id bases), ... */
 int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, size_t* bytes);
 /* Live kernel timing for bench.py's roofline line: while enabled, every launch of the dominant
- * kernel family (the dense NT GEMMs with M = B*N rows: gemm_nt_wide_kernel in bf16 mode,
- * gemm_nt_big_kernel<float> in fp32 mode) is bracketed by hipEvents on the launch stream.  pnp_profile_read
+ * kernel family (the dense NT GEMMs with M = B*N rows: gemm_nt_x3_kernel<EPI> in the benchmarked split-bf16 mode
+ * (csrc/gemm_x3.hip; three bf16 MFMAs per product, so the MFMA work issued is 3x the FLOPs reported here),
+ * gemm_nt_wide_kernel<EPI> in the bf16 throughput mode, gemm_nt_big_kernel<float> in the exact-fp32 mode) is
+ * bracketed by hipEvents on the launch stream.  pnp_profile_read
  * synchronises those events and returns launches, summed algorithmic FLOPs (2*M*N*K) and summed
  * kernel milliseconds since the last enable.  Off by default (no events on the hot path).  on = 1 brackets every launch,
  * on = n > 1 every n-th launch of the family (an event pair costs ~2.5 us of stream serialisation; sums cover the bracketed
@@ -246,7 +248,10 @@ int pnp_profile_enable(pnp_engine* e, int32_t on);
 int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms);
 /* Same for a pipeline stage: 0 = the dense GEMMs (as pnp_profile_read), 1 = the DenseCRF mean-field iterations
  * (PnP.py:1066-1072: splat / lattice blur / slice + update kernels of one batch, bracketed as a whole); `work` is
- * FLOPs for stage 0 and algorithmic bytes for stage 1: iterations x (2 x 9 + 2) x K x H x W x 4. */
+ * FLOPs for stage 0 and algorithmic bytes for stage 1, per mean-field iteration (2 x 9 + 2) x K x H x W x 4 (SURVEY.md 8d:
+ * splat + slice over the 3 + 6 simplex vertices of a pixel, Q read + written) + 2 x (2 x M_gauss + 3 x M_bilateral) x K x 4 (the
+ * lattice term: the value arrays of the M_* lattice points read and written once per two-axis blur pass), summed over the
+ * iterations of the bracketed batches. */
 int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* launches, double* work, double* ms);
 /* Stand-alone operator entry points used by the parity tests (device pointers, see csrc/). */
 int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,

@@ -6,6 +6,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 namespace pnp {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -193,3 +195,56 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 #define PNP_ERR_HIP (-5)
 #define PNP_ERR_STATE (-1)
 #define PNP_ERR_NOMEM (-12)
+
+// ---- per-device one-time set-up of a launcher.  A process may hold engines on several devices (pnp_config.device) and drives
+// them from several host threads: what a launcher needs once -- the opt-in of a kernel to more than 64 KB of dynamic LDS, the
+// CU count behind a persistent grid, an occupancy query -- is kept per DEVICE ORDINAL of the calling thread's current
+// device, and a failure is returned, never cached.
+namespace pnp {
+constexpr int kMaxDevices = 32;
+
+static inline int current_device() {
+    int d = -1;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDevices) ? d : -1;
+}
+
+// `done`: one bit per device ordinal, owned by the call site (function-local static).  hipFuncSetAttribute is idempotent, so two
+// threads that race on the first call of a device both set it.
+static inline int lds_opt_in(std::atomic<uint32_t>& done, const void* kernel, int bytes) {
+    const int d = current_device();
+    if (d < 0) return -5;
+    if (done.load(std::memory_order_acquire) & (1u << d)) return 0;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return -5;
+    done.fetch_or(1u << d, std::memory_order_release);
+    return 0;
+}
+
+// compute units of the current device (0: the query failed; not cached then)
+static inline int device_cu_count() {
+    static std::atomic<int> cus[kMaxDevices];
+    const int d = current_device();
+    if (d < 0) return 0;
+    int n = cus[d].load(std::memory_order_relaxed);
+    if (n) return n;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 0;
+    n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    cus[d].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+// a small per-device cache of one int per call site (occupancy-derived grids): 0 = not yet computed on this device
+struct PerDeviceInt {
+    std::atomic<int> v[kMaxDevices];
+    template <typename F> int get(F compute) {
+        const int d = current_device();
+        if (d < 0) return compute();
+        int n = v[d].load(std::memory_order_relaxed);
+        if (!n) {
+            n = compute();
+            v[d].store(n, std::memory_order_relaxed);
+        }
+        return n;
+    }
+};
+}  // namespace pnp

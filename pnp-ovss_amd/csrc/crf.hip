@@ -27,9 +27,10 @@ namespace pnp {
 template <int D> struct KeyPack;
 template <> struct KeyPack<2> { static constexpr int BITS = 16; };
 template <> struct KeyPack<5> { static constexpr int BITS = 11; };
-// The image index of the batch is placed above the coordinate bits (bit IMG_SHIFT..), so ONE
-// device-wide stable radix sort groups the entries of every image (a segmented sort with a few huge
-// segments is several times slower).  5 x 11 + 6 bits <= 61: at most 64 images per prepared batch.
+// The image index of the batch sits above the coordinate bits (bit IMG_SHIFT..).  It is NOT sorted on: the entries arrive
+// image by image, so crf_build_lattice runs sort.hip's stable radix sort segmented by image over the coordinate bits alone;
+// the image bits stay in the keys for what reads them afterwards (mark_heads: a run never spans two images; the neighbour
+// search compares whole keys).  5 x 11 + 6 bits <= 61: at most 64 images per prepared batch.
 constexpr int IMG_SHIFT = 55;
 constexpr int IMG_BITS = 6;
 
@@ -948,7 +949,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     }
     const int nbe = 1024;
     hipLaunchKernelGGL(mark_heads_kernel, dim3(nbe, B), dim3(256), 0, s, keys_b, d_imgs, D + 1, head);
-    if (device_scan_i32(head, incl, ent_total, true, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
+    if (const int r = device_scan_i32(head, incl, ent_total, true, temp, temp_bytes, s); r != PNP_OK) return r;
     hipLaunchKernelGGL(scatter_ids_kernel, dim3(nbe, B), dim3(256), 0, s, keys_b, L.vals, head, incl, d_imgs, D + 1, B,
                        ent_total, L.offset, L.seg_start, L.ukeys, L.idbase);
     if (D == 2)
@@ -976,7 +977,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     {   // lattice points are numbered image by image: segmented by image over (Z-order position, vertex) = bits [0, 40)
         size_t seg2[(1 << IMG_BITS) + 1];
         for (int b = 0; b <= B; b++) seg2[b] = (size_t)h_idbase[b];
-        if (radix_sort_pairs(fkey, skey, fid, sid, (size_t)M, 0, 40, seg2, B, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
+        if (const int r = radix_sort_pairs(fkey, skey, fid, sid, (size_t)M, 0, 40, seg2, B, temp, temp_bytes, s); r != PNP_OK) return r;
     }
     hipLaunchKernelGGL(rank_kernel, dim3(1024), dim3(256), 0, s, sid, M, rank);
     hipLaunchKernelGGL(renumber_points_kernel, dim3(1024), dim3(256), 0, s, rank, L.seg_start, n1k, n2k, L.cap, M, D + 1,
@@ -987,7 +988,7 @@ int crf_build_lattice(int D, const CrfLattice& L, const PostDesc* d_imgs, const 
     int* len = reinterpret_cast<int*>(keys_a);
     uint32_t* vals2 = reinterpret_cast<uint32_t*>(keys_b);
     hipLaunchKernelGGL(seg_len_kernel, dim3(1024), dim3(256), 0, s, L.seg_lo, L.seg_hi, M, len);
-    if (device_scan_i32(len, incl, (size_t)M, false, temp, temp_bytes, s) != PNP_OK) return PNP_ERR_HIP;
+    if (const int r = device_scan_i32(len, incl, (size_t)M, false, temp, temp_bytes, s); r != PNP_OK) return r;
     hipLaunchKernelGGL(move_segments_kernel, dim3(4096), dim3(256), 0, s, L.vals, incl, M, D + 1, L.bary, L.seg_lo, L.seg_hi, vals2, L.ent);
     hipLaunchKernelGGL(set_segments_kernel, dim3(1024), dim3(256), 0, s, incl, M, L.seg_lo, L.seg_hi);
     if (hipMemcpyAsync(L.vals, vals2, ent_total * sizeof(uint32_t), hipMemcpyDeviceToDevice, s) != hipSuccess) return PNP_ERR_HIP;
@@ -1002,10 +1003,8 @@ static float crf_alpha(int D) { return 1.0f / (1 + powf(2, (float)-D)); }
 // re-fetches from HBM every Q / value row the first one had in L2.
 template <typename F>
 static int resident_grid(F kernel, int threads, size_t smem) {
-    int dev = 0, cus = 256, occ = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    int cus = device_cu_count(), occ = 0;
+    if (cus <= 0) cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, threads, smem) != hipSuccess || occ < 1) occ = 1;
     const int per_xcd = (cus / 8 > 0 ? cus / 8 : 1) * occ;
     return 8 * (per_xcd < 256 ? per_xcd : 256);
@@ -1039,8 +1038,9 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
     const int k4 = (max_kp + 3) / 4;
 #define PNP_SPLAT(LPP_, MULTI_)                                                                                                  \
     do {                                                                                                                      \
-        static const int nbs0 = resident_grid(crf_splat_kernel<LPP_, 0, MULTI_>, 256, 0);                                     \
-        static const int nbs1 = resident_grid(crf_splat_kernel<LPP_, 1, MULTI_>, 256, 0);                                     \
+        static PerDeviceInt g0_, g1_;                        /* per device ordinal (common.h) */                              \
+        const int nbs0 = g0_.get([] { return resident_grid(crf_splat_kernel<LPP_, 0, MULTI_>, 256, 0); });                    \
+        const int nbs1 = g1_.get([] { return resident_grid(crf_splat_kernel<LPP_, 1, MULTI_>, 256, 0); });                    \
         if (L.which == 0) hipLaunchKernelGGL((crf_splat_kernel<LPP_, 0, MULTI_>), dim3(nbs0), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg); \
         else hipLaunchKernelGGL((crf_splat_kernel<LPP_, 1, MULTI_>), dim3(nbs1), dim3(256), 0, s, L, d_imgs, Q, va, img0, nimg);              \
     } while (0)
@@ -1049,7 +1049,9 @@ int crf_filter(const CrfLattice& L, const PostDesc* d_imgs, int img0, int nimg, 
     else if (k4 <= 32) PNP_SPLAT(32, false);
     else PNP_SPLAT(32, true);
 #undef PNP_SPLAT
-    static const int nb2 = resident_grid(crf_blur4x2_kernel, 256, 0), nb1 = resident_grid(crf_blur4_kernel, 256, 0);
+    static PerDeviceInt gb2, gb1;                            // per device ordinal (common.h)
+    const int nb2 = gb2.get([] { return resident_grid(crf_blur4x2_kernel, 256, 0); });
+    const int nb1 = gb1.get([] { return resident_grid(crf_blur4_kernel, 256, 0); });
     float* src = va;
     float* dst = vb;
     // axes in pairs through the fused two-axis kernel (bilateral: 3 passes for 6 axes; Gaussian: one pair + one single):
@@ -1097,18 +1099,20 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
     }
     (void)max_pixels;
     // (the occupancy depends on the tile's LDS bytes: queried per distinct size, a handful per process)
-    static size_t grid_smem[8];
-    static int grid_nb[8], grid_n = 0;
-    static std::mutex grid_mu;                               // engines of different host threads share the table
+    static size_t grid_smem[16];
+    static int grid_dev[16], grid_nb[16], grid_n = 0;
+    static std::mutex grid_mu;                               // engines of different host threads / devices share the table
     int nbu = 0;
     {
+        const int dev = current_device();
         std::lock_guard<std::mutex> lk(grid_mu);
         for (int i = 0; i < grid_n; i++)
-            if (grid_smem[i] == smem) nbu = grid_nb[i];
+            if (grid_smem[i] == smem && grid_dev[i] == dev) nbu = grid_nb[i];
         if (!nbu) {
             nbu = resident_grid(crf_update_kernel, 256, smem);
-            if (grid_n < 8) {
+            if (grid_n < 16) {
                 grid_smem[grid_n] = smem;
+                grid_dev[grid_n] = dev;
                 grid_nb[grid_n++] = nbu;
             }
         }

@@ -79,6 +79,9 @@ struct pnp_engine {
     // ---- activations
     int ldq = 0;               // row stride (elements) of the fused q|k|v buffer
     float* x0 = nullptr;       // [M, D] token embeddings of drop iteration 0 (patch embed + pos, cls row): later iterations reuse them
+    // what the reusable state was computed from (embed == 1 call): an embed == 2 call that does not match recomputes instead
+    struct { const float* images = nullptr; const int64_t* ids = nullptr; const int64_t* mask = nullptr; int B = 0, L = 0, ld = 0;
+             bool vit = false, text = false; } reuse;
     void *patches = nullptr, *xn = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *h1 = nullptr, *embT = nullptr;
     float *x = nullptr, *emb32 = nullptr;
     void *Knat = nullptr, *Vnat = nullptr, *Kt = nullptr, *Vt = nullptr;
@@ -704,6 +707,7 @@ extern "C" int pnp_finalize_weights(pnp_engine* e) {
 // images are those of the last embed-1 call with the patches of d_dropped zeroed: reuse the copy (embed_reuse_kernel)
 static int vit_forward_impl(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream, int embed);
 extern "C" int pnp_vit_forward(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream) {
+    if (e) e->reuse.vit = false;                 // the operator form writes e->x: x0 no longer describes what follows
     return vit_forward_impl(e, d_images, d_dropped, B, stream, 0);
 }
 static int vit_forward_impl(pnp_engine* e, const float* d_images, const uint8_t* d_dropped, int32_t B, void* stream, int embed) {
@@ -713,6 +717,7 @@ static int vit_forward_impl(pnp_engine* e, const float* d_images, const uint8_t*
     hipStream_t s = (hipStream_t)stream;
     const int D = e->D, N = e->N, M = B * N, F = D * e->c.vit_mlp_ratio, bf = e->bf;
     const int ldv = e->c.max_batch * e->Npad;
+    if (embed == 2 && !(e->reuse.vit && e->reuse.images == d_images && e->reuse.B == B)) embed = 0;   // stale: recompute
     if (embed == 2 && d_dropped) {
         hipLaunchKernelGGL(embed_reuse_kernel, dim3(2048), dim3(256), 0, s, (const float*)e->x0, d_dropped, (const float*)e->patch_b,
                            (const float*)e->pos, e->x, M, N, D / 4);
@@ -725,7 +730,12 @@ static int vit_forward_impl(pnp_engine* e, const float* d_images, const uint8_t*
         g.bias = e->patch_b; g.resid = e->pos; g.ldr = D; g.out_f32 = e->x; g.ldo = D; g.row_div = e->PP;
         KCHK(e, egemm(e, bf, g, s));
     }
-    if (embed == 1) HIPCHK(e, hipMemcpyAsync(e->x0, e->x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (embed == 1) {
+        HIPCHK(e, hipMemcpyAsync(e->x0, e->x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        e->reuse.images = d_images;
+        e->reuse.B = B;
+        e->reuse.vit = true;
+    }
     }
     const float scale = 1.0f / sqrtf(64.f);
     if (e->x3) {
@@ -885,6 +895,7 @@ static int text_forward_impl(pnp_engine* e, const int64_t* d_ids, const int64_t*
                              float* d_logits, void* stream, bool reuse_prefix);
 extern "C" int pnp_text_forward_xattn(pnp_engine* e, const int64_t* d_ids, const int64_t* d_mask, int32_t ld, int32_t B,
                                       int32_t L, float* d_logits, void* stream) {
+    if (e) e->reuse.text = false;
     return text_forward_impl(e, d_ids, d_mask, ld, B, L, d_logits, stream, false);
 }
 static int text_forward_impl(pnp_engine* e, const int64_t* d_ids, const int64_t* d_mask, int32_t ld, int32_t B, int32_t L,
@@ -897,6 +908,9 @@ static int text_forward_impl(pnp_engine* e, const int64_t* d_ids, const int64_t*
     const int H = e->H, I = e->I, TL = e->TL, R = B * L, bf = e->bf, N = e->N, D = e->D;
     const int ldv = e->c.max_batch * e->Npad;
     (void)D;
+    if (reuse_prefix && !(e->reuse.text && e->reuse.ids == d_ids && e->reuse.mask == d_mask && e->reuse.B == B && e->reuse.L == L &&
+                          e->reuse.ld == ld))
+        reuse_prefix = false;                    // not the captions whose prefix is in place: compute it
     if (!reuse_prefix) {
         KCHK(e, text_embed(d_ids, ld, e->word, e->tpos, e->temb, B, L, H, e->c.enc_token_id, e->c.vocab, s));
         KCHK(e, layernorm(bf, e->temb, e->eln_w, e->eln_b, e->c.txt_ln_eps, R, H, e->h0, e->h0T, nullptr, nullptr, s));
@@ -1044,6 +1058,12 @@ static int compute_gradcam_impl(pnp_engine* e, const float* d_images, const uint
     // probabilities of layer 0's self-attention, which are in place as well)
     r = text_forward_impl(e, d_ids, d_mask, ld, B, L, d_logits, stream, embed == 2);
     if (r) return r;
+    if (embed == 1) {                            // the prefix now in place belongs to these captions
+        e->reuse.ids = d_ids; e->reuse.mask = d_mask; e->reuse.L = L; e->reuse.ld = ld;
+        e->reuse.text = true;
+    } else if (embed == 0) {
+        e->reuse.text = false;
+    }
     r = pnp_xattn_grad_layer(e, B, L, layer, stream);
     if (r) return r;
     return pnp_gradcam_gather(e, d_mask, ld, B, L, head, d_out, stream);

@@ -325,9 +325,8 @@ template <typename T, int BM, int BN, int WTM, int WTN, int NS, bool PIPE = true
 static int launch_big(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const size_t smem = (size_t)NS * (BM + BN) * 128;
-    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (attr != hipSuccess) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>), (int)smem) != PNP_OK) return PNP_ERR_HIP;
     hipLaunchKernelGGL((gemm_nt_big_kernel<T, BM, BN, WTM, WTN, NS, PIPE>), dim3(nbm * nbn), dim3((BM / WTM) * (BN / WTN) * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
@@ -761,16 +760,10 @@ static int wide_epilogue_kind(const GemmArgs& g) {
 template <int EPI>
 static int launch_wide(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
-    static const int n_cu = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }();
+    const int n_cu = device_cu_count();
     if (!n_cu) return PNP_ERR_HIP;
-    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideSmem);
-    if (attr != hipSuccess) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(gemm_nt_wide_kernel<EPI>), kWideSmem) != PNP_OK) return PNP_ERR_HIP;
     const int ntiles = nbm * nbn;
     int cap = n_cu;
 #ifdef PNP_DEV
@@ -983,9 +976,8 @@ template <int NW, int KS, int NS = 4>
 static int launch_small_x3_t(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 63) / 64, nbn = g.N / 64;
     constexpr int smem = NS * 4 * 64 * 64 * KS;
-    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_small_x3_kernel<NW, KS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (attr != hipSuccess) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(gemm_nt_small_x3_kernel<NW, KS, NS>), smem) != PNP_OK) return PNP_ERR_HIP;
     hipLaunchKernelGGL((gemm_nt_small_x3_kernel<NW, KS, NS>), dim3(nbm * nbn), dim3(NW * 64), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }
@@ -1127,9 +1119,8 @@ template <typename T, int BM, int BN>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + BM - 1) / BM, nbn = g.N / BN;
     const size_t smem = 2 * (BM + BN) * 128;
-    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (attr != hipSuccess) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(gemm_nt_kernel<T, BM, BN>), (int)smem) != PNP_OK) return PNP_ERR_HIP;
     hipLaunchKernelGGL((gemm_nt_kernel<T, BM, BN>), dim3(nbm * nbn), dim3(256), smem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
 }

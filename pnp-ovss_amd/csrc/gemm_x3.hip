@@ -145,7 +145,11 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
             "s_mov_b64 exec, %1"
             : "=&v"(voff), "=&s"(saved)
             : "v"(soff[op * 2 + rg]), "s"((uint32_t)kt * 64), "s"(base), "s"(lds), "s"(on)
-            : "memory", "scc");        // (m0 is reserved: nothing else in this kernel uses it)
+            : "memory", "scc");        // m0: hipcc treats it as RESERVED -- it cannot be named in a clobber list ("inline asm
+                                       // clobber list contains reserved registers", the entry is ignored) and the compiler itself
+                                       // writes it only for its own LDS-DMA / GPR-indexing / LDS-param instructions, none of which this
+                                       // kernel contains: tests/test_cabi_cpu.py::test_m0_is_written_only_by_the_asm_lds_dma checks the
+                                       // disassembly of the shipped code object for exactly that
     };
     auto stamp = [&](int slot) {
         if (g.stamps && tid == 0) {
@@ -479,16 +483,10 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
 template <int EPI>
 static int launch_x3(const GemmArgs& g, hipStream_t s) {
     const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
-    static const int n_cu = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-        return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }();
+    const int n_cu = device_cu_count();
     if (!n_cu) return PNP_ERR_HIP;
-    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_x3_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, kWideSmem);
-    if (attr != hipSuccess) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(gemm_nt_x3_kernel<EPI>), kWideSmem) != PNP_OK) return PNP_ERR_HIP;
     const int ntiles = nbm * nbn;
     int cap = n_cu;
 #ifdef PNP_DEV

@@ -852,9 +852,8 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
     size_t d0, d1;
     lds_for(nt1, d0, d1);
     lds1 = d1;
-    // function-local static: initialised once, thread-safely (engines are driven from several host threads)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_axis_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr != hipSuccess) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(blur_axis_kernel), 160 * 1024) != PNP_OK) return PNP_ERR_HIP;
     const int tiles0 = ((maxW + 63) / 64) * ((maxH + 32 * nt0 - 1) / (32 * nt0));
     const int tiles1 = ((maxW + 64 * nt1 - 1) / (64 * nt1)) * ((maxH + 31) / 32);
     hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles0, Kmax, B), dim3(256 * nt0), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius, nt0);
@@ -865,9 +864,8 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
 int unary_from_maps(const float* maps, const PostDesc* desc, float* unary, int B, int maxHW, int max_kp, int group, hipStream_t s) {
     const int nb = (maxHW + 255) / 256 < 256 ? (maxHW + 255) / 256 : 256;
     const size_t smem = (size_t)256 * (max_kp + 1) * sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(unary_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       160 * 1024);
-    if (attr != hipSuccess) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(unary_kernel), 160 * 1024) != PNP_OK) return PNP_ERR_HIP;
     if (max_kp >= 32) {                                                    // wide rows: nothing parked in LDS
         const int nbw = (maxHW + 255) / 256 < 2048 ? (maxHW + 255) / 256 : 2048;
         hipLaunchKernelGGL(unary_wide_kernel, dim3(nbw, B), dim3(256), 0, s, maps, desc, unary, group);

@@ -507,7 +507,8 @@ __global__ __launch_bounds__(768) void vit_attn32_x3_kernel(const bf16* __restri
                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)sb);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(loff), "s"(sbu),
                          "s"(__builtin_amdgcn_readfirstlane((int)lds))
-                         : "memory");
+                         : "memory");      // (m0 is a reserved register to hipcc: not nameable as a clobber; the shipped code
+                                           //  object is checked for foreign m0 uses by tests/test_cabi_cpu.py)
         }
     };
 

@@ -1,6 +1,7 @@
 """Self-check of a compute mode against the reference's own outputs: the committed pipeline fixtures
-(tests/golden/pipeline_{voc,psc}.npz -- inputs by seed, and the label maps the REFERENCE's save_img_union_attention
-produced for them, PnP.py:290-521) run through the HIP engine in the given mode; returns how many label pixels differ.
+(tests/golden/pipeline_{voc,psc,voc_large}.npz -- inputs by seed, and the label maps the REFERENCE's
+save_img_union_attention produced for them, PnP.py:290-521; `pipeline_voc_large.npz` is the benchmarked geometry:
+BLIP-ITM-large 336^2 with the full 20-class prompt) run through the HIP engine in the given mode; returns how many label pixels differ.
 
 Used by bench.py to print, next to the headline number, the label-flip fraction of the benchmarked mode against the
 reference fixtures (tests/test_hip_parity.py::test_end_to_end_labels_vs_reference_run asserts the same comparison with the
@@ -17,7 +18,7 @@ from .hip import Engine
 from .tokenizer import SynthTokenizer
 
 
-def fixture_label_flips(mode, golden_dir, fixtures=("pipeline_voc.npz", "pipeline_psc.npz"), device=0):
+def fixture_label_flips(mode, golden_dir, fixtures=("pipeline_voc.npz", "pipeline_psc.npz", "pipeline_voc_large.npz"), device=0):
     """-> {"pixels": total compared, "differing": count, "frac": ..., "per_fixture": {...}} over both branches (1-drop,
     N-drop) x both un-CRF'd post-process forms the fixtures hold (blur, none) of every fixture image."""
     dev = torch.device("cuda", device)
@@ -28,9 +29,9 @@ def fixture_label_flips(mode, golden_dir, fixtures=("pipeline_voc.npz", "pipelin
         data_type = str(g["data_type"])
         cats = {int(k): v for k, v in json.loads(str(g["cats"])).items()}
         nms = list(cats.values())
-        B = 3
-        _, imgs = synth.synth_images(B, cfg.img_size, seed=int(g["image_seed"]))
         sizes = [tuple(int(v) for v in s) for s in g["sizes"]]
+        B = len(sizes)
+        _, imgs = synth.synth_images(B, cfg.img_size, seed=int(g["image_seed"]))
         rng = np.random.default_rng(int(g["org_seed"]))
         org = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
         gpt = json.loads(str(g["gpt"]))
@@ -46,7 +47,8 @@ def fixture_label_flips(mode, golden_dir, fixtures=("pipeline_voc.npz", "pipelin
         e = Engine(cfg, max_batch=4, max_text_len=32, stash_layer=7, mode=mode, device=device)
         try:
             e.load_state_dict(synth.synth_state_dict(cfg, int(g["weight_seed"])))
-            e.post_reserve(4, 4 * 128 * 128, 128 * 128, 8, 0)
+            e.post_reserve(max(B, 4), max(sum(h * w for h, w in sizes), 4 * 128 * 128), max(max(h * w for h, w in sizes), 128 * 128),
+                           max(max(len(b) for b in best) + 1, 8), 0)
             g0, agg, _, _ = e.drop_loop(torch.from_numpy(imgs).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(mask).to(dev),
                                         L, 9, 4)
             plans, luts, bgs = [], [], []

@@ -13,6 +13,7 @@ Fixtures (inputs are regenerated from seeds by pnp_ovss.synth; only outputs are 
   merge_tokens.npz    Mean_over_filtered_label_tokens on split / unsplit captions
   pipeline_voc.npz    save_img_union_attention end to end (blur / no post-process; CRF is not
   pipeline_psc.npz    importable here -> parity unpinned for CRF), hist .npy contents
+  pipeline_voc_large.npz  the same at the HEADLINE geometry: BLIP-ITM-large 336^2, 20-class prompt, labels + hists only
   pipeline_coco_object.npz / pipeline_coco_stuff.npz   the COCO driver's save_img_union_attention
                       (PnP_OVSS_0514_updated_segmentation_coco.py) at drop_iter 4 (N-drop only) and 2 (both branches)
   gpt_parse_coco.json the COCO driver's Load_predicted_classes on sampled strings (category id -> cats position)
@@ -262,14 +263,26 @@ VOC_CATS = {1: "aeroplane", 2: "bicycle", 3: "bird", 4: "boat", 5: "bottle", 6: 
             16: "pottedplant", 17: "sheep", 18: "sofa", 19: "train", 20: "tvmonitor"}
 
 
-def _gen_pipeline(data_type, img_ids, cats, fname):
-    """save_img_union_attention end to end on 3 synthetic images of different original sizes
-    (GPT-4o class strings are the reference's shipped JSON for the chosen ids)."""
-    cfg = C.blip_itm_small(128)
-    m, itm, tok = _model(cfg, seed=4)
-    B = 3
-    _, imgs = synth.synth_images(B, cfg.img_size, seed=6)
-    sizes = [(90, 120), (128, 128), (75, 100)]   # H+W > 128: torch generic bilinear kernel
+def _gen_pipeline(data_type, img_ids, cats, fname, cfg=None, weight_seed=4, image_seed=6,
+                  sizes=((90, 120), (128, 128), (75, 100)), gpt_override=None, keep_prepost=True):
+    """save_img_union_attention end to end on synthetic images of different original sizes
+    (GPT-4o class strings are the reference's shipped JSON for the chosen ids unless `gpt_override` supplies strings of
+    the same format for some ids -- then the reference reads a JSON file holding the merged dict from a temp home_dir)."""
+    cfg = cfg or C.blip_itm_small(128)
+    m, itm, tok = _model(cfg, seed=weight_seed)
+    sizes = [tuple(s) for s in sizes]            # H+W > 128: torch generic bilinear kernel
+    B = len(sizes)
+    assert B == len(img_ids)
+    _, imgs = synth.synth_images(B, cfg.img_size, seed=image_seed)
+    gpt = json.load(open(RL.REF + f"/GPT4o_classification/{data_type}_classification_noboundary.json"))
+    home = RL.REF
+    if gpt_override:
+        gpt = dict(gpt)
+        gpt.update(gpt_override)
+        home = tempfile.mkdtemp()
+        os.makedirs(os.path.join(home, "GPT4o_classification"))
+        with open(os.path.join(home, "GPT4o_classification", f"{data_type}_classification_noboundary.json"), "w") as f:
+            json.dump({k: gpt[k] for k in img_ids}, f)
     rng = np.random.default_rng(99)
     org = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for h, w in sizes]
     gts = [rng.integers(0, len(cats) + 1, size=(h, w)).astype(np.float32) for h, w in sizes]
@@ -297,7 +310,7 @@ def _gen_pipeline(data_type, img_ids, cats, fname):
         tmp = tempfile.mkdtemp()
         args = argparse.Namespace(img_size=cfg.img_size, drop_iter=4, max_att_block_num=8, prune_att_head="9",
                                   del_patch_num="sort_thresh005", data_type=data_type, postprocess=pp,
-                                  threshold=0.15, home_dir=RL.REF, save_path=tmp)
+                                  threshold=0.15, home_dir=home, save_path=tmp)
         tok500 = tok(["x"] * B, padding="max_length", max_length=500, return_tensors="pt")
         norm_imgs = torch.zeros(B, cfg.img_size, cfg.img_size, 3)
         with np.errstate(all="ignore"):
@@ -309,20 +322,30 @@ def _gen_pipeline(data_type, img_ids, cats, fname):
         for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
             f = os.path.join(tmp, d, f"img_{img_ids[0]}_max_blocknum_8_atthead_9.npy")
             out[f"{d}_{tag}"] = np.load(f)
-        for i, r in enumerate(rec):
+        for i, r in enumerate(rec if keep_prepost else []):
             out[f"prepost_{tag}_{i}"] = r          # order: 1-drop imgs 0..B-1 then N-drop imgs 0..B-1
         for br, name in enumerate(("1drop", "ndrop")):
             for i in range(B):
                 out[f"labels_{name}_{tag}_{i}"] = labs[br][i]
-    gpt = json.load(open(RL.REF + f"/GPT4o_classification/{data_type}_classification_noboundary.json"))
-    np.savez_compressed(os.path.join(HERE, fname), cfg=json.dumps(cfg.as_dict()), weight_seed=4,
-                        image_seed=6, img_ids=np.array(img_ids), gpt=json.dumps({k: gpt[k] for k in img_ids}),
+    np.savez_compressed(os.path.join(HERE, fname), cfg=json.dumps(cfg.as_dict()), weight_seed=weight_seed,
+                        image_seed=image_seed, img_ids=np.array(img_ids), gpt=json.dumps({k: gpt[k] for k in img_ids}),
                         cats=json.dumps(cats), data_type=data_type, sizes=np.array(sizes), org_seed=99, **out)
     print(fname, {k: getattr(v, "shape", None) for k, v in out.items()})
 
 
 def gen_pipeline_voc():
     _gen_pipeline("voc", ["2007_008374", "2007_000129", "2007_009419"], VOC_CATS, "pipeline_voc.npz")
+
+
+def gen_pipeline_voc_large():
+    """The HEADLINE geometry end to end through the reference: BLIP-ITM-large 336^2, VOC rules, drop_iter 4, B = 2 --
+    image 0 carries the full 20-class prompt of the benchmark (a GPT-4o-format string naming every VOC class at 95 %) at
+    the benchmark's 336 x 336 original size, image 1 the reference's shipped string of a real id at a 375 x 500 original.
+    Label maps and .npy histograms only (the K x H x W pre-post maps would be 10 MB each)."""
+    all20 = "[" + ", ".join(f"{i}: {n}" for i, n in VOC_CATS.items()) + "], [" + ", ".join(["95%"] * 20) + "]"
+    _gen_pipeline("voc", ["2007_000033", "2007_000129"], VOC_CATS, "pipeline_voc_large.npz", cfg=C.blip_itm_large(336),
+                  weight_seed=0, image_seed=77, sizes=((336, 336), (375, 500)), gpt_override={"2007_000033": all20},
+                  keep_prepost=False)
 
 
 def gen_pipeline_psc():
@@ -695,7 +718,7 @@ def gen_preprocess_cases():
     print("preprocess_cases:", len(cases), "cases, Pillow", PIL.__version__)
 
 
-GENS = dict(gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, gradcam_large_768=gen_gradcam_large_768, droploop_small=gen_droploop_small,
+GENS = dict(pipeline_voc_large=gen_pipeline_voc_large, gradcam_small=gen_gradcam_small, gradcam_large=gen_gradcam_large, gradcam_large_768=gen_gradcam_large_768, droploop_small=gen_droploop_small,
             merge_tokens=gen_merge_tokens, pipeline_voc=gen_pipeline_voc, pipeline_psc=gen_pipeline_psc,
             pipeline_coco_object=gen_pipeline_coco_object, pipeline_coco_stuff=gen_pipeline_coco_stuff,
             gpt_parse_coco=gen_gpt_parse_coco, gpt_parse=gen_gpt_parse, tokenizer=gen_tokenizer,
@@ -710,6 +733,6 @@ if __name__ == "__main__":
     for name, fn in GENS.items():
         if a.only and name != a.only:
             continue
-        if a.skip_large and name in ("gradcam_large", "gradcam_large_768", "droploop_large"):
+        if a.skip_large and name in ("gradcam_large", "gradcam_large_768", "droploop_large", "pipeline_voc_large"):
             continue
         fn()

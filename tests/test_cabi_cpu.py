@@ -71,3 +71,62 @@ def test_operator_entry_points_validate_arguments_without_a_gpu(lib):
     n = None
     assert lib.pnp_op_gemm_x3a(n, 64, n, n, 64, 8, 64, 64, n, n, 0, n, 64, 0, n, 0, n) == -22
     assert lib.pnp_op_gemm_x3(n, n, 64, n, n, 64, 8, 64, 64, n, 0, n, 0, n, 0, n, n, 0, 0, 0, 0, n) == -22
+
+
+def _gfx950_code_objects(lib_path, tmpdir):
+    """The gfx950 code objects inside the library's .hip_fatbin section (one clang offload bundle per translation unit:
+    magic, u64 entry count, per entry u64 offset / u64 size / u64 triple length / triple)."""
+    import struct
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat = os.path.join(tmpdir, "fat.bin")
+    subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", lib_path, fat])
+    d = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, at = [], d.find(magic)
+    while at >= 0:
+        (n,) = struct.unpack_from("<Q", d, at + len(magic))
+        p = at + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", d, p)
+            triple = d[p + 24: p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and size:
+                out.append(d[at + off: at + off + size])
+        at = d.find(magic, at + 1)
+    return out
+
+
+def test_m0_is_written_only_by_the_asm_lds_dma(lib, tmp_path):
+    """The split-bf16 GEMM and attention kernels issue their LDS-DMA as inline asm that writes m0 (the LDS base of a piece).
+    hipcc reserves m0 and rejects it in a clobber list, so the asm relies on the compiler having no m0 use of its own in those
+    kernels.  Checked on the shipped code object: in every gemm_nt_x3 / vit_attn32_x3 kernel each instruction
+    that names m0 is `s_mov_b32 m0, <sgpr>` and the next vector-memory instruction behind it is a global_load_lds."""
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not in this image")
+    checked = 0
+    for i, co in enumerate(_gfx950_code_objects(LIB, str(tmp_path))):
+        f = tmp_path / f"co{i}.o"
+        f.write_bytes(co)
+        asm = subprocess.run([objdump, "-d", str(f)], capture_output=True, text=True, check=True).stdout
+        name, body = None, {}
+        for line in asm.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                name = m.group(1)
+                body[name] = []
+            elif name and line.startswith("\t"):
+                body[name].append(line.split("//")[0].strip())
+        for k, ins in body.items():
+            if "gemm_nt_x3_kernel" not in k and "vit_attn32_x3_kernel" not in k:
+                continue
+            uses = [j for j, t in enumerate(ins) if re.search(r"\bm0\b", t)]
+            assert uses, f"{k}: no m0 write found (the asm LDS-DMA should be there)"
+            for j in uses:
+                assert re.match(r"s_mov_b32 m0, s\d+$", ins[j]), f"{k}: foreign m0 use `{ins[j]}`"
+                nxt = next((t for t in ins[j + 1: j + 6] if t.startswith(("global_", "buffer_", "flat_", "ds_"))), "")
+                assert nxt.startswith("global_load_lds_dwordx4"), f"{k}: `{ins[j]}` is followed by `{nxt}`"
+            checked += 1
+    assert checked >= 6, checked            # five GEMM epilogue variants + the attention kernel(s)
