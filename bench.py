@@ -86,7 +86,8 @@ def parse_args(argv=None):
                     help="skip the label comparison of the mode against the reference's fixtures (profiling runs: it adds small launches)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short records of the other BASELINE configs")
     ap.add_argument("--other-steps", type=int, default=3, help="timed steps of each other-config record (after one warm-up)")
-    ap.add_argument("--cpu-images", type=int, default=3, help="images of the cpu_baseline sample (after one warm-up image)")
+    ap.add_argument("--cpu-images", type=int, default=20, help="images of the cpu_baseline sample, rounded up to a whole number per "
+                    "worker process (SURVEY 8d: >= 20 after warm-ups)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: exercise launcher + rendezvous + broadcast / all-reduce / gather on CPU tensors")
@@ -143,36 +144,78 @@ def launch_ranks(n, argv):
 
 # ------------------------------------------------------------------------------------------ CPU baseline
 
-def cpu_baseline(cfg, seed_w, n_images=3, noise=NOISE):
-    """The oracle (numpy + C restatement of the reference path) timed on this box's host cores on a
-    bounded sample of the headline workload: one warm-up image, then `n_images` images, full path (4 drop
-    iterations, both branches, blur + CRF).  Reported next to the GPU number; not the optimisation target.
-    SURVEY.md 8d's >= 20 images after 3 warm-ups would take ~6 minutes of the bench's budget at the measured
-    ~16 s per image, so the sample is bounded and says so; the in-container timing of the ACTUAL reference code
-    (SURVEY.md 6 / BASELINE.md 2: it cannot travel to the GPU box) rides along as a labelled constant."""
+def host_cpu_share():
+    """Host cores this process may actually use: the cgroup CPU quota when one is set (a GPU box hands a one-GPU job a share
+    of the host, not the cores os.cpu_count() lists), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(cfg, seed_w, n_images=20, noise=NOISE, cores=None, W=None):
+    """The oracle (numpy + C restatement of the reference path) timed on this box's host cores, IMAGE-PARALLEL (SURVEY.md 8d:
+    all host cores, >= 20 images after warm-ups): a pool of worker processes (oracle/cpu_worker.py), two BLAS threads each,
+    sharing one memory-mapped copy of the weights; every worker runs a warm-up image, then all start together and process
+    their share of the images one at a time through the full path (4 drop iterations, 1-drop + N-drop branches, blur + CRF).
+    images/sec = images / wall time from the common start to the last worker's end.  Reported next to the GPU number; not
+    the optimisation target.  The in-container timing of the ACTUAL reference code (SURVEY.md 6 / BASELINE.md 2: it cannot
+    travel to the GPU box) rides along as a labelled constant."""
+    import shutil
+    import tempfile
     from pnp_ovss import synth
-    from oracle import pipeline_np as OP
-    W = synth.synth_state_dict(cfg, seed_w)
-    nc, img = CONFIGS["voc"]["classes"], CONFIGS["voc"]["img"]
-    pieces1 = [[f"t{i}" for i in range(nc)]]
-    best1 = [list(range(nc))]
-
-    def run(n, seed):
-        rgb, imgs = synth.synth_images(n, img, seed=seed, noise=noise)
-        ids, mask = synth.synth_tokens(cfg, [nc] * n, seed=seed)
+    from oracle import cpu_worker as CW
+    share = cores or host_cpu_share()
+    threads = 2 if share >= 4 else 1
+    workers = max(1, min(share // threads, 32))
+    per = max(1, -(-n_images // workers))                     # images per worker; every worker gets the same count
+    total = per * workers
+    if W is None:
+        W = synth.synth_state_dict(cfg, seed_w)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="pnp_cpu_baseline_", dir=base)
+    procs = []
+    try:
+        CW.save_weights(W, d)
+        nc, img = CONFIGS["voc"]["classes"], CONFIGS["voc"]["img"]
+        for i in range(workers):
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", "--weights", d, "--images", str(per), "--seed",
+                                           str(1234 + i), "--threads", str(threads), "--noise", str(noise), "--classes", str(nc),
+                                           "--img", str(img)], cwd=ROOT, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True))
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu_baseline worker did not come up")
         t0 = time.perf_counter()
-        OP.segment_batch(W, cfg, imgs, ids, mask, pieces1 * n, best1 * n, list(rgb), [(img, img)] * n, data_type="voc",
-                         drop_iter=DROP_ITER, layer=LAYER, head=HEAD, threshold=THRESH, mode="blur+crf")
-        return time.perf_counter() - t0
-
-    warm = run(1, 99)
-    dt = run(n_images, 1234)
-    return {"value": n_images / dt, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n_images} image(s) 336x336 in one batch after a 1-image warm-up ({warm:.1f} s), 20-class prompt, "
-                      f"drop_iter=4, 1-drop + N-drop blur+CRF, numpy/OpenBLAS + gcc oracle, {dt:.1f} s "
-                      f"(= {dt / n_images:.1f} s per image; 20 images + 3 warm-ups as SURVEY 8d words it would be "
-                      f"~{23 * dt / n_images:.0f} s of this run, so the rate is quoted from this bounded sample, no extrapolation "
-                      f"beyond 1/x)",
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        outs = [json.loads(p.stdout.readline()) for p in procs]
+        dt = time.perf_counter() - t0
+        for p in procs:
+            p.wait()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(d, ignore_errors=True)
+    per_img = [t for o in outs for t in o["seconds"]]
+    warm = [o["warmup_seconds"] for o in outs]
+    return {"value": total / dt, "unit": "images/sec", "cores": workers * threads, "kind": "port",
+            "workers": workers, "threads_per_worker": threads, "host_cores_available": share, "host_cores_listed": os.cpu_count(),
+            "sample": f"{total} images 336x336 ({per} per worker, one at a time) on {workers} worker processes x {threads} BLAS threads "
+                      f"after one warm-up image per worker (drop_iter 1, {min(warm):.1f}-{max(warm):.1f} s), 20-class prompt, drop_iter=4, "
+                      f"1-drop + N-drop blur+CRF, numpy/OpenBLAS + gcc oracle: {dt:.1f} s wall from the common start to the last "
+                      f"worker's end; {min(per_img):.1f}-{max(per_img):.1f} s per image inside a worker",
             "reference_in_container": {
                 "value": 1.0 / (4 * 9.07 + 0.38 + 1.23), "unit": "images/sec", "cores": 8, "kind": "reference",
                 "machine": "build container (8 host cores, torch 2.10 CPU), NOT this box",
@@ -331,14 +374,17 @@ def run_rank(a):
 
         def make_engine(self):
             flat, shapes, _ = weights_for(self.cfg)
+            # the engines of a workload (batches in flight) run on ONE converted weight copy: the first one loads it, the
+            # others are created on it (pnp_create_shared: activations + workspace of their own)
             e = Engine(self.cfg, max_batch=self.B, max_text_len=max(32, (self.L + 7) // 8 * 8), stash_layer=LAYER, mode=self.dtype,
-                       device=local)
-            sd, o = {}, 0
-            for n, shp in shapes.items():
-                k = int(np.prod(shp))
-                sd[n] = flat[o:o + k].view(*shp)
-                o += k
-            e.load_state_dict(sd)
+                       device=local, share_weights_with=self.engines[0] if self.engines else None)
+            if not self.engines:
+                sd, o = {}, 0
+                for n, shp in shapes.items():
+                    k = int(np.prod(shp))
+                    sd[n] = flat[o:o + k].view(*shp)
+                    o += k
+                e.load_state_dict(sd)
             e.post_reserve(self.B, self.B * self.img * self.img, self.img * self.img, self.K, self.chunk)
             self.engines.append(e)
             return e
@@ -542,7 +588,8 @@ def run_rank(a):
                "dtype": wl.dtype,
                "pipelines": {"batches_in_flight": P,
                              "note": "P engines / HIP streams / host threads take the timed steps round-robin; every step is "
-                                     "the whole path over one batch", "one_batch_at_a_time": seq},
+                                     "the whole path over one batch; the engines share one weight copy", "one_batch_at_a_time": seq,
+                             "engine_device_bytes": [int(e.allocated_bytes()) for e in wl.engines[:max(P, 1)]]},
                "roofline": roof, "crf": roofline_crf(crf, steps, ppp)}
         rec["roofline"]["measured_in"] = rec["crf"]["measured_in"] = (
             "one-batch-at-a-time pass of the same workload in this run (%d timed steps, %.1f ms per step)" % (steps, seq["ms_per_step"]))
@@ -650,7 +697,13 @@ def run_rank(a):
                 torch.cuda.empty_cache()
                 out["other_configs"][name] = r3
         if single and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C.blip_itm_large(336), 0, a.cpu_images, a.noise)
+            flat, shapes, _ = weights_for(C.blip_itm_large(336))          # the same seeded weights the engines run on
+            host, W_cpu, o = flat.cpu().numpy(), {}, 0
+            for n, shp in shapes.items():
+                k = int(np.prod(shp))
+                W_cpu[n] = host[o:o + k].reshape(shp)
+                o += k
+            out["cpu_baseline"] = cpu_baseline(C.blip_itm_large(336), 0, a.cpu_images, a.noise, W=W_cpu)
         print(json.dumps(out))
         sys.stdout.flush()
     else:

@@ -39,7 +39,8 @@ typedef struct pnp_config {
     float txt_ln_eps;
     int32_t vocab, max_pos, enc_token_id;
     int32_t max_batch;      /* images per step (--batch_size, PnP.py:58) */
-    int32_t max_text_len;   /* longest tokenised caption the engine must hold (<= 192) */
+    int32_t max_text_len;   /* longest tokenised caption the engine must hold (<= 512 = BERT's position table; the reference
+                             * tokenises to max_length 500, PnP.py:271,318) */
     int32_t stash_layer;    /* args.max_att_block_num - 1 (PnP.py:619): text layer whose P and dL/dP are kept */
     int32_t compute_bf16;   /* arithmetic of the dense contractions:
                              *   0  exact fp32 MFMA everywhere (the reference's arithmetic; parity mode)
@@ -55,6 +56,12 @@ typedef struct pnp_config {
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 int pnp_create(const pnp_config* cfg, pnp_engine** out);
+/* A second engine on the donor's WEIGHTS (same device, compute mode and model geometry; cfg->stash_layer >= the donor's;
+ * max_batch / max_text_len free): allocates activations and workspace only, never calls pnp_load_weight /
+ * pnp_finalize_weights, and keeps the weights alive past the donor's pnp_destroy (shared ownership).  What `--pipelines P`
+ * / bench.py's batches in flight run on: P engines, one weight copy (the reference holds one replica per process,
+ * PnP.py:1212-1218; several batches in flight per GPU are this build's addition). */
+int pnp_create_shared(const pnp_config* cfg, pnp_engine* donor, pnp_engine** out);
 void pnp_destroy(pnp_engine* e);
 const char* pnp_last_error(const pnp_engine* e);          /* valid until the next call on e */
 size_t pnp_workspace_bytes(const pnp_config* cfg);         /* device bytes pnp_create will allocate */

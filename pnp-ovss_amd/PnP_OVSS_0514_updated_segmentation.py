@@ -8,6 +8,15 @@ here torchrun or the built-in spawn), same outputs: per-batch confusion matrices
 Calculate_mIoU.py reads them.  New: `--data_type synthetic` (no dataset on disk), `--dtype`,
 `--checkpoint`, `--vocab`; the final histogram is additionally all-reduced over RCCL and printed.
 
+Multi-rank (the reference: DDP-constructor broadcast PnP.py:1218, file-system reduce :513-520):
+  * `--weights_sync broadcast` (default): rank 0 loads the checkpoint, every rank receives rank 0's weights as one flat fp32
+    buffer over RCCL and the ranks compare a digest of what they hold -- a mismatch stops the run on every rank;
+    `checksum`: every rank loads the checkpoint itself (what the reference does in front of its DDP wrapper) and only the
+    digest is compared; `none`: no collective at start-up;
+  * the image count and the confusion matrix of the summary line are all-reduced;
+  * `--gather_labels`: the final (N-drop) uint8 label maps of every rank are gathered on rank 0 over RCCL and written to
+    `{save_path}/label_maps.npz` (image id -> H x W), north_star's mask-gather.
+
 Device work happens in libpnp_hip.so via pnp_ovss.model.Segmenter; this file is host orchestration.
 """
 import argparse
@@ -71,6 +80,14 @@ def get_args_parser():
                    help="batches in flight on this GPU: P model replicas, each with its own HIP stream and host thread, take the "
                         "batches as they come (the text side and kernel tails of one batch run beside another batch's dense "
                         "kernels: +10-14 %% images/s at P = 3; results are identical, the per-batch lines may print out of order)")
+    p.add_argument("--weights_sync", default="broadcast", choices=["broadcast", "checksum", "none"],
+                   help="world_size > 1: RCCL broadcast of rank 0's weights + digest check (default), digest check of per-rank loads, or nothing")
+    p.add_argument("--gather_labels", action="store_true",
+                   help="gather every rank's final label maps on rank 0 (RCCL) and write {save_path}/label_maps.npz")
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on ROCm)")
+    p.add_argument("--share_gpu", action="store_true",
+                   help="diagnostic: every rank uses cuda:0 (rehearses world_size > 1 on a one-GPU box with --backend gloo; RCCL "
+                        "refuses two ranks on one device)")
     p.add_argument("--synthetic_images", default=70, type=int)
     p.add_argument("--max_batches", default=0, type=int)
     return p
@@ -81,15 +98,71 @@ def ddp_setup(args, rank, world_size):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(args.master_port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    backend = args.backend if torch.cuda.is_available() else "gloo"
     dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
+
+
+def make_weights_sync(args, rank, world_size):
+    """The start-up collective on the flat fp32 weight buffer (pnp_ovss.model.build_model(sync=...)): broadcast of rank 0's
+    weights (the reference's DDP(model) constructor, PnP.py:1218) and / or a digest comparison that fails on EVERY rank."""
+    from pnp_ovss.model import weights_digest
+    info = {}
+
+    def sync(flat):
+        if world_size <= 1 or args.weights_sync == "none":
+            return
+        t0 = time.perf_counter()
+        if args.weights_sync == "broadcast":
+            dist.broadcast(flat, src=0)
+        dg = weights_digest(flat)
+        every = [torch.zeros_like(dg) for _ in range(world_size)]
+        dist.all_gather(every, dg)
+        torch.cuda.synchronize()
+        info.update(mode=args.weights_sync, bytes=int(flat.numel()) * 4, ms=1e3 * (time.perf_counter() - t0),
+                    digest=[int(v) for v in dg.cpu()])
+        bad = [r for r, d in enumerate(every) if not torch.equal(d, every[0])]
+        if bad:
+            raise SystemExit(f"rank {rank}: weights differ from rank 0's on rank(s) {bad} after --weights_sync {args.weights_sync} "
+                             f"(digests {[[int(v) for v in d.cpu()] for d in every]})")
+    return sync, info
+
+
+def gather_label_maps(kept, rank, world_size, dev, save_path):
+    """north_star's mask-gather: every rank's final uint8 label maps to rank 0 in ONE padded device-to-device gather
+    (RCCL; the ids / sizes travel as a small object gather), written as {save_path}/label_maps.npz (image id -> H x W).
+    Replaces nothing in the reference, which keeps label maps only inside save_img_union_attention (PnP.py:390-399)."""
+    ids = sorted(kept)
+    shapes = [tuple(int(v) for v in kept[i].shape) for i in ids]
+    buf = torch.cat([kept[i].reshape(-1) for i in ids]) if ids else torch.zeros(0, dtype=torch.uint8, device=dev)
+    metas = [(ids, shapes)]
+    bufs = [buf]
+    if world_size > 1:
+        metas = [None] * world_size
+        dist.all_gather_object(metas, (ids, shapes))
+        cap = max(sum(h * w for h, w in m[1]) for m in metas)
+        pad = torch.zeros(max(cap, 1), dtype=torch.uint8, device=dev)
+        pad[: buf.numel()] = buf
+        bufs = [torch.empty_like(pad) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    out = {}
+    for (r_ids, r_shapes), b in zip(metas, bufs):
+        host_b, o = b.cpu().numpy(), 0
+        for i, (h, w) in zip(r_ids, r_shapes):
+            out[i] = host_b[o:o + h * w].reshape(h, w)
+            o += h * w
+    np.savez_compressed(os.path.join(save_path, "label_maps.npz"), **out)
+    return {"images": len(out), "bytes_per_rank": [int(sum(h * w for h, w in m[1])) for m in metas]}
 
 
 def main(rank, world_size, args):
     tic = time.perf_counter()
     if world_size > 1:
         ddp_setup(args, rank, world_size)
-    torch.cuda.set_device(rank)
+    dev_idx = 0 if args.share_gpu else rank
+    args.device_index = dev_idx                 # what the dataset's device-side decode / resize runs on
+    torch.cuda.set_device(dev_idx)
     if args.prune_att_head is None:
         raise SystemExit("--prune_att_head is required (reference :277)")
     if args.del_patch_num is None or "sort_thresh" not in args.del_patch_num:
@@ -99,10 +172,16 @@ def main(rank, world_size, args):
     stash_layer = args.max_att_block_num - 1
     if args.ensemble_blocks is not None and "saveall" in args.ensemble_blocks:
         stash_layer = int(args.layer) - 1 if args.layer else 0         # lowest layer of the sweep (default: all 12)
+    sync, sync_info = make_weights_sync(args, rank, world_size)
+    receive_only = world_size > 1 and args.weights_sync == "broadcast" and rank != 0
     model, vis_processors, text_processors = load_model_and_preprocess(
-        "blip_image_text_matching", "large", device=rank, is_eval=True, img_size=args.img_size,
+        "blip_image_text_matching", "large", device=dev_idx, is_eval=True, img_size=args.img_size,
         max_batch=args.batch_size, stash_layer=stash_layer, mode=args.dtype,
-        checkpoint=args.checkpoint, vocab=args.vocab, max_text_len=ds.max_text_len)
+        checkpoint=args.checkpoint, vocab=args.vocab, max_text_len=ds.max_text_len,
+        sync=sync if world_size > 1 and args.weights_sync != "none" else None, receive_only=receive_only)
+    if rank == 0 and sync_info:
+        print(f"weights: --weights_sync {sync_info['mode']} of {sync_info['bytes'] / 1e9:.2f} GB over {world_size} ranks in "
+              f"{sync_info['ms']:.0f} ms, digests equal", flush=True)
     coco = args.data_type in ("coco_object", "coco_stuff")
     n_class = host.coco_n_class(args.data_type) if coco else len(ds.cats) + 1        # PnPc.py:597-600 / PnP.py:1115
     seg = Segmenter(model, args.data_type if args.data_type != "synthetic" else "voc", n_class, threshold=args.threshold,
@@ -115,12 +194,12 @@ def main(rank, world_size, args):
     pairs = [(b + 1, h) for b in range(stash_layer, 12) for h in range(12)] if sweep else [(args.max_att_block_num, int(args.prune_att_head))]
     for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
         Path(f"{args.save_path}/{d}/").mkdir(parents=True, exist_ok=True)
-    replicas = [(model, seg)]          # --pipelines: P model replicas (weights loaded per replica)
+    replicas = [(model, seg)]          # --pipelines: P engines on ONE weight copy (pnp_create_shared: the first model is the donor)
     for _ in range(max(0, args.pipelines - 1)):
         m2, _, _ = load_model_and_preprocess(
-            "blip_image_text_matching", "large", device=rank, is_eval=True, img_size=args.img_size,
+            "blip_image_text_matching", "large", device=dev_idx, is_eval=True, img_size=args.img_size,
             max_batch=args.batch_size, stash_layer=stash_layer, mode=args.dtype,
-            checkpoint=args.checkpoint, vocab=args.vocab, max_text_len=ds.max_text_len)
+            vocab=args.vocab, max_text_len=ds.max_text_len, donor=model)
         replicas.append((m2, Segmenter(m2, args.data_type if args.data_type != "synthetic" else "voc", n_class,
                                        threshold=args.threshold, postprocess=args.postprocess,
                                        max_pixels_per_image=ds.max_pixels, max_channels=ds.max_channels,
@@ -128,8 +207,9 @@ def main(rank, world_size, args):
     if args.pipelines > 1 and rank == 0:
         free_b, total_b = torch.cuda.mem_get_info()
         used = [m.engine.allocated_bytes() for m, _ in replicas]
-        print(f"--pipelines {args.pipelines}: {sum(used) / 2**30:.1f} GiB in {len(used)} replicas "
-              f"({max(used) / 2**30:.1f} GiB each: weights + workspace), {free_b / 2**30:.1f} GiB of {total_b / 2**30:.0f} GiB free", flush=True)
+        print(f"--pipelines {args.pipelines}: {sum(used) / 2**30:.1f} GiB in {len(used)} engines "
+              f"(the first holds the one weight copy: {used[0] / 2**30:.1f} GiB; the others workspace only: {min(used) / 2**30:.1f} GiB), "
+              f"{free_b / 2**30:.1f} GiB of {total_b / 2**30:.0f} GiB free", flush=True)
         if free_b < 0.05 * total_b:
             print("warning: less than 5 % of device memory free: lower --pipelines or --batch_size", flush=True)
     n_img = 0
@@ -154,6 +234,12 @@ def main(rank, world_size, args):
               "miou all_drop", host.scores_from_hist(hn)["Mean IoU"] if ln else None, flush=True)
         return hn if ln else h1
 
+    kept = {}                                   # --gather_labels: image id -> uint8 label map on the device (last (layer, head) wins)
+
+    def keep_labels(img_ids, maps):
+        for i, m in zip(img_ids, maps):
+            kept[str(i)] = m.to(torch.uint8).clone()        # the launch's views are only valid until the next launch
+
     if args.pipelines > 1:
         # P replicas (model + Segmenter + stream + host thread) consume the batch stream; each batch still runs the whole
         # path on one replica, into that replica's own pair of confusion matrices (bench.py --pipelines is the same scheme)
@@ -163,7 +249,7 @@ def main(rank, world_size, args):
 
         def worker(rep):
             try:
-                torch.cuda.set_device(rank)
+                torch.cuda.set_device(dev_idx)
                 sg = rep[1]
                 ring = (torch.zeros_like(sg.hist_1drop), torch.zeros_like(sg.hist_ndrop), torch.cuda.Event())
                 with torch.cuda.stream(torch.cuda.Stream()):
@@ -187,6 +273,9 @@ def main(rank, world_size, args):
                             ring[0].zero_()
                             ring[1].zero_()
                             l1, ln = sg.launch(pargs, batch["imgs"], prep, run_1drop=True, hists=ring[:2])
+                            if args.gather_labels:
+                                with lock:
+                                    keep_labels(batch["img_ids"], ln if ln is not None else l1)
                             ring[2].record()
                             last = finish((batch["img_ids"], layer, head, l1 is not None, ln is not None, ring))
                         with lock:
@@ -221,6 +310,8 @@ def main(rank, world_size, args):
             ring[0].zero_()
             ring[1].zero_()
             l1, ln = seg.launch(pargs, batch["imgs"], prep, run_1drop=True, hists=ring[:2])
+            if args.gather_labels:
+                keep_labels(batch["img_ids"], ln if ln is not None else l1)
             ring[2].record()
             job = (batch["img_ids"], layer, head, l1 is not None, ln is not None, ring)
             if pending is not None:
@@ -233,13 +324,25 @@ def main(rank, world_size, args):
         ds.total_hist += finish(pending)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_loop
-    total = torch.from_numpy(ds.total_hist).to(torch.device("cuda", rank))
+    dev = torch.device("cuda", dev_idx)
+    total = torch.from_numpy(ds.total_hist).to(dev)
+    count = torch.tensor([n_img], device=dev, dtype=torch.int64)
     if world_size > 1:
         dist.all_reduce(total)                  # RCCL reduce of the confusion matrix (the reference sums files offline)
+        dist.all_reduce(count)                  # images actually processed (DistributedSampler pads: a few count twice, as in the reference)
+    gathered = None
+    if args.gather_labels:
+        gathered = gather_label_maps(kept, rank, world_size, dev, args.save_path)
     if rank == 0:
         s = host.scores_from_hist(total.cpu().numpy())
-        print(json.dumps({"images": n_img * world_size, "images_per_sec_rank0": n_img / dt, "Mean IoU": float(s["Mean IoU"]),
-                          "Pixel Accuracy": float(s["Pixel Accuracy"]), "FWIoU": float(s["Frequency Weighted IoU"])}))
+        line = {"images": int(count.item()), "images_rank0": n_img, "ranks": world_size, "images_per_sec_rank0": n_img / dt,
+                "Mean IoU": float(s["Mean IoU"]), "Pixel Accuracy": float(s["Pixel Accuracy"]),
+                "FWIoU": float(s["Frequency Weighted IoU"]), "pixels": float(total.sum().item())}
+        if sync_info:
+            line["weights_sync"] = {k: sync_info[k] for k in ("mode", "bytes", "ms")}
+        if gathered is not None:
+            line["gathered_label_maps"] = gathered
+        print(json.dumps(line))
         print(f"Time: total running time for {n_img} images/rank {time.perf_counter() - tic:0.4f} seconds")
     if world_size > 1:
         dist.destroy_process_group()

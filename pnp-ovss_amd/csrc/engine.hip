@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -51,10 +52,25 @@ struct VitLayerW {
     void *qkv_w, *proj_w, *fc1_w, *fc2_w;
 };
 
+// Device allocations that hold WEIGHTS (converted GEMM weights, biases, LayerNorm parameters, embeddings): read-only once
+// finalized, so several engines of a process may use one copy (pnp_create_shared); freed with the last engine that holds it.
+struct WeightStore {
+    int device = 0;
+    std::vector<void*> allocs;
+    size_t bytes = 0;
+    ~WeightStore() {
+        (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+    }
+};
+
 }  // namespace
 
 struct pnp_engine {
     pnp_config c{};
+    std::shared_ptr<WeightStore> wstore;       // owner(s) of every weight allocation below
+    bool to_store = false;                     // dalloc target: the weight store (true) or this engine's own list
+    bool shares_weights = false;               // created by pnp_create_shared: the weights belong to a donor's store
     int bf = 0;                // 1: bf16 storage / bf16 MFMA everywhere
     int x3 = 0;                // 1: split-bf16 ("bf16x3") ViT Linears + cross K/V projections, everything else as fp32 mode
     size_t esz = 4;
@@ -179,7 +195,12 @@ int dalloc(pnp_engine* e, T** out, size_t count, bool zero = false) {
     const size_t bytes = (count * sizeof(T) + 255) / 256 * 256;
     if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) return fail(e, PNP_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
     if (zero && hipMemset(p, 0, bytes ? bytes : 256) != hipSuccess) return fail(e, PNP_ERR_HIP, "hipMemset failed");
-    e->allocs.push_back(p);
+    if (e->to_store && e->wstore) {
+        e->wstore->allocs.push_back(p);
+        e->wstore->bytes += bytes;
+    } else {
+        e->allocs.push_back(p);
+    }
     e->alloc_bytes += bytes;
     *out = reinterpret_cast<T*>(p);
     return PNP_OK;
@@ -351,11 +372,30 @@ extern "C" void pnp_destroy(pnp_engine* e) {
     delete e;
 }
 
-extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
+static int create_impl(const pnp_config* cfg, pnp_engine* donor, pnp_engine** out);
+extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) { return create_impl(cfg, nullptr, out); }
+extern "C" int pnp_create_shared(const pnp_config* cfg, pnp_engine* donor, pnp_engine** out) {
+    if (!donor) return PNP_ERR_ARG;
+    return create_impl(cfg, donor, out);
+}
+static int create_impl(const pnp_config* cfg, pnp_engine* donor, pnp_engine** out) {
     if (!cfg || !out) return PNP_ERR_ARG;
     pnp_engine* e = new pnp_engine();
     *out = e;
     e->c = *cfg;
+    if (donor) {
+        const pnp_config& d = donor->c;
+        if (!donor->finalized) return fail(e, PNP_ERR_STATE, "pnp_create_shared: the donor's weights are not finalized");
+        if (d.device != cfg->device || d.compute_bf16 != cfg->compute_bf16 || d.img_size != cfg->img_size || d.patch != cfg->patch ||
+            d.vit_dim != cfg->vit_dim || d.vit_depth != cfg->vit_depth || d.vit_heads != cfg->vit_heads ||
+            d.vit_mlp_ratio != cfg->vit_mlp_ratio || d.txt_hidden != cfg->txt_hidden || d.txt_layers != cfg->txt_layers ||
+            d.txt_heads != cfg->txt_heads || d.txt_inter != cfg->txt_inter || d.vocab != cfg->vocab || d.max_pos != cfg->max_pos ||
+            d.vit_ln_eps != cfg->vit_ln_eps || d.txt_ln_eps != cfg->txt_ln_eps)
+            return fail(e, PNP_ERR_ARG, "pnp_create_shared: device, compute mode and model geometry must equal the donor's");
+        if (cfg->stash_layer < d.stash_layer)
+            return fail(e, PNP_ERR_ARG, "pnp_create_shared: stash_layer %d below the donor's %d (its transposed backward weights "
+                        "exist for layers >= %d only)", cfg->stash_layer, d.stash_layer, d.stash_layer);
+    }
     const pnp_config& c = e->c;
     if (c.compute_bf16 < 0 || c.compute_bf16 > 2) return fail(e, PNP_ERR_ARG, "compute_bf16 must be 0 (fp32), 1 (bf16) or 2 (split-bf16)");
     e->bf = c.compute_bf16 == 1 ? 1 : 0;
@@ -369,7 +409,8 @@ extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
     if (c.vit_dim % 128 || c.txt_hidden % 128 || c.txt_inter % 128 || (c.vit_dim * c.vit_mlp_ratio) % 128)
         return fail(e, PNP_ERR_ARG, "widths must be multiples of 128");
     if (c.vit_dim > 1024 || c.txt_hidden > 1024) return fail(e, PNP_ERR_ARG, "LayerNorm width > 1024 unsupported");
-    if (c.max_text_len < 5 || c.max_text_len > 192) return fail(e, PNP_ERR_ARG, "max_text_len must be in [5,192]");
+    if (c.max_text_len < 5 || c.max_text_len > 512 || c.max_text_len > c.max_pos)
+        return fail(e, PNP_ERR_ARG, "max_text_len must be in [5, min(512, max_pos = %d)]", c.max_pos);
     if (c.stash_layer < 0 || c.stash_layer >= c.txt_layers) return fail(e, PNP_ERR_ARG, "stash_layer out of range");
     if (c.max_batch <= 0) return fail(e, PNP_ERR_ARG, "max_batch must be positive");
     HIPCHK(e, hipSetDevice(c.device));
@@ -458,6 +499,22 @@ extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
     KCHK(e, dalloc(e, &e->G, B * L * (size_t)e->PP));
     KCHK(e, dalloc(e, &e->dropped, B * (size_t)e->PP, true));
     KCHK(e, dalloc(e, &e->logits_scratch, B * 2));
+    if (donor) {
+        // weights: the donor's device copies (read-only after finalize); this engine owns activations and workspace only
+        e->wstore = donor->wstore;
+        e->shares_weights = true;
+        e->cls = donor->cls; e->pos = donor->pos; e->patch_b = donor->patch_b; e->vnorm_w = donor->vnorm_w; e->vnorm_b = donor->vnorm_b;
+        e->word = donor->word; e->tpos = donor->tpos; e->eln_w = donor->eln_w; e->eln_b = donor->eln_b;
+        e->itm_w = donor->itm_w; e->itm_b = donor->itm_b; e->ck_b = donor->ck_b; e->cv_b = donor->cv_b;
+        e->patch_w = donor->patch_w; e->ck_w = donor->ck_w; e->cv_w = donor->cv_w;
+        e->vit = donor->vit;
+        e->txt = donor->txt;
+        e->finalized = true;
+        return PNP_OK;
+    }
+    e->wstore = std::make_shared<WeightStore>();
+    e->wstore->device = c.device;
+    e->to_store = true;
     // small fp32 params
     KCHK(e, dalloc(e, &e->cls, D));
     KCHK(e, dalloc(e, &e->pos, (size_t)e->N * D));
@@ -483,6 +540,7 @@ extern "C" int pnp_create(const pnp_config* cfg, pnp_engine** out) {
         KCHK(e, dalloc(e, &t.cq_b, H)); KCHK(e, dalloc(e, &t.co_b, H)); KCHK(e, dalloc(e, &t.cln_w, H)); KCHK(e, dalloc(e, &t.cln_b, H));
         KCHK(e, dalloc(e, &t.i_b, I)); KCHK(e, dalloc(e, &t.o_b, H)); KCHK(e, dalloc(e, &t.oln_w, H)); KCHK(e, dalloc(e, &t.oln_b, H));
     }
+    e->to_store = false;
     return PNP_OK;
 }
 
@@ -570,6 +628,7 @@ bool resolve(pnp_engine* e, const std::string& n, Slot& s) {
 extern "C" int pnp_load_weight(pnp_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim,
                                int32_t on_device) {
     if (!e || !name || !data || !shape) return PNP_ERR_ARG;
+    if (e->shares_weights) return fail(e, PNP_ERR_STATE, "this engine uses a donor's weights (pnp_create_shared)");
     if (e->finalized) return fail(e, PNP_ERR_STATE, "weights already finalized");
     HIPCHK(e, hipSetDevice(e->c.device));
     Slot s;
@@ -596,6 +655,8 @@ extern "C" int pnp_finalize_weights(pnp_engine* e) {
     if (!e) return PNP_ERR_ARG;
     if (e->finalized) return PNP_OK;
     HIPCHK(e, hipSetDevice(e->c.device));
+    e->to_store = true;                        // everything allocated from here to the end of the call is a weight
+    struct StoreOff { pnp_engine* e; ~StoreOff() { e->to_store = false; } } store_off{e};
     const int D = e->D, H = e->H, I = e->I, TL = e->TL;
     auto stage = [&](const std::string& n) -> const float* {
         auto it = e->named.find("stage:" + n);
@@ -927,7 +988,7 @@ static int text_forward_impl(pnp_engine* e, const int64_t* d_ids, const int64_t*
             g.bias = w.qkv_b; g.out_t = a.qkv; g.ldo_t = 3 * H;
             KCHK(e, tgemm(e, g, s));
         }
-        KCHK(e, text_self_attn(bf, a.qkv, d_mask, ld, e->ctx_s, stash ? a.Ps : nullptr, B, L, H, s));
+        KCHK(e, text_self_attn(bf, a.qkv, d_mask, ld, e->ctx_s, stash ? a.Ps : nullptr, e->dS, B, L, H, s));
         {
             GemmArgs g = G_(e->ctx_s, H, w.so_w, H, R, H, H);
             g.bias = w.so_b; g.resid = h; g.ldr = H; g.out_f32 = e->tmp; g.ldo = H;

@@ -72,7 +72,9 @@ int vit_attention_x3(const void* qkv_hi, const void* qkv_lo, int ld_qk, int D, v
 // text_kernels.hip
 int text_embed(const int64_t* ids, int ld_ids, const float* word, const float* pos, float* out, int B, int L, int H,
                int enc_id, int vocab, hipStream_t s);
-int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, void* ctx, float* probs, int B, int L,
+// scratch: [B, heads, L, L] floats, used when L > 192 and probs is null (the long-caption form passes a row's probabilities
+// through global memory)
+int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, void* ctx, float* probs, float* scratch, int B, int L,
                    int H, hipStream_t s);
 int text_self_attn_bwd(int bf, const void* qkv, const float* dctx, const float* probs, float* ds_scratch, void* dqkv,
                        int B, int L, int H, hipStream_t s);

@@ -26,7 +26,7 @@ __global__ void text_embed_kernel(const int64_t* __restrict__ ids, int ld_ids, c
 }
 
 // ------------------------------------------------------------------------------------------
-// Text self-attention (L <= 192 tokens, head_dim 64): one workgroup per (head, image), k/v staged
+// Text self-attention (L <= 192 tokens -- longer captions: text_self_attn_long_kernel below --, head_dim 64): one workgroup per (head, image), k/v staged
 // in LDS as fp32 (row stride 65 -> conflict-free column walks), one wave per query row.
 // qkv: [B*L, 3H] (q | k | v), mask: (B, ld_mask) int64 (1 = attend), additive -10000 like
 // med.py:851.  ctx: [B*L, H] T.  probs (optional): fp32 [B, heads, L, L] stash for the backward.
@@ -176,6 +176,164 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
             dv += p * bs[i * 65 + lane];
         }
         dqkv[(row0 + j) * 3 * H + H + h * 64 + lane] = from_f32<T>(dk * 0.125f);
+        dqkv[(row0 + j) * 3 * H + 2 * H + h * 64 + lane] = from_f32<T>(dv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Long captions, TXT_MAX_L < L <= TXT_LONG_L (the reference tokenises to max_length = 500 and BERT's position table ends at 512:
+// PnP.py:271,318, B/blip_image_text_matching.py:48,234).  Two fp32 [L][65] arrays no longer fit the 160 KB of LDS, so the same
+// one-wave-per-row scheme runs in PHASES over ONE staged array; what a later phase needs of an earlier one goes through global
+// memory -- the probabilities through the layer's stash (or a scratch of the same shape), dS through the scratch the short
+// kernel uses too.  Same arithmetic and summation order per row as the short kernels.
+constexpr int TXT_LONG_L = 512;
+constexpr int TXT_LONG_CH = TXT_LONG_L / 64;
+
+template <typename T>
+__device__ __forceinline__ void stage_rows65(float* dst, const T* __restrict__ src, size_t ld, int L, int tid) {
+    for (int i = tid; i < L * 64; i += 256) {
+        const int j = i >> 6, d = i & 63;
+        dst[j * 65 + d] = to_f32(src[(size_t)j * ld + d]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void text_self_attn_long_kernel(const T* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                                  int ld_mask, T* __restrict__ ctx, float* __restrict__ pglob,
+                                                                  int L, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* st = reinterpret_cast<float*>(smem);          // [L][65]: keys, then values
+    float* pw = st + L * 65;                             // [4 waves][TXT_LONG_L]
+    float* madd = pw + 4 * TXT_LONG_L;                   // [TXT_LONG_L]
+    float* qw = madd + TXT_LONG_L;                       // [4 waves][64]
+    const int h = blockIdx.x, b = blockIdx.y, nh = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row0 = (size_t)b * L;
+    float* P = pglob + ((size_t)b * nh + h) * L * L;
+    stage_rows65(st, qkv + row0 * 3 * H + H + h * 64, (size_t)3 * H, L, tid);
+    for (int j = tid; j < L; j += 256) madd[j] = (1.0f - (float)mask[(size_t)b * ld_mask + j]) * -10000.0f;
+    __syncthreads();
+    float* myq = qw + wave * 64;
+    for (int i = wave; i < L; i += 4) {                  // phase 1: scores, softmax, probabilities -> global
+        myq[lane] = to_f32(qkv[(row0 + i) * 3 * H + h * 64 + lane]);
+        __builtin_amdgcn_wave_barrier();
+        float sc[TXT_LONG_CH];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < TXT_LONG_CH; c++) {
+            const int j = lane + c * 64;
+            float acc = -INFINITY;
+            if (j < L) {
+                acc = 0.f;
+                for (int d = 0; d < 64; d++) acc += myq[d] * st[j * 65 + d];
+                acc = acc * 0.125f + madd[j];
+            }
+            sc[c] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < TXT_LONG_CH; c++) {
+            sc[c] = (lane + c * 64 < L) ? __expf(sc[c] - mx) : 0.f;
+            sum += sc[c];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int c = 0; c < TXT_LONG_CH; c++) {
+            const int j = lane + c * 64;
+            if (j < L) P[(size_t)i * L + j] = sc[c] * inv;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                                     // every wave is done with the keys
+    stage_rows65(st, qkv + row0 * 3 * H + 2 * H + h * 64, (size_t)3 * H, L, tid);
+    __syncthreads();
+    float* myp = pw + wave * TXT_LONG_L;
+    for (int i = wave; i < L; i += 4) {                  // phase 2: ctx = P.V (a lane reads back exactly what it wrote)
+        for (int j = lane; j < L; j += 64) myp[j] = P[(size_t)i * L + j];
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        for (int j = 0; j < L; j++) o += myp[j] * st[j * 65 + lane];
+        ctx[(row0 + i) * H + h * 64 + lane] = from_f32<T>(o);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void text_self_attn_bwd_long_kernel(const T* __restrict__ qkv, const float* __restrict__ dctx,
+                                                                      const float* __restrict__ probs,
+                                                                      float* __restrict__ ds_scratch, T* __restrict__ dqkv,
+                                                                      int L, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* st = reinterpret_cast<float*>(smem);          // [L][65]: v, k, q, dctx in turn
+    float* pw = st + L * 65;                             // [4 waves][TXT_LONG_L]
+    float* qw = pw + 4 * TXT_LONG_L;                     // [4 waves][64]
+    const int h = blockIdx.x, b = blockIdx.y, nh = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row0 = (size_t)b * L;
+    const float* P = probs + ((size_t)b * nh + h) * L * L;
+    float* dS = ds_scratch + ((size_t)b * nh + h) * L * L;
+    float* myp = pw + wave * TXT_LONG_L;
+    float* myg = qw + wave * 64;
+    // phase A1 (values staged): dP_ij = dctx_i . v_j ; dS = P (dP - sum_j dP P) -> global
+    stage_rows65(st, qkv + row0 * 3 * H + 2 * H + h * 64, (size_t)3 * H, L, tid);
+    __syncthreads();
+    for (int i = wave; i < L; i += 4) {
+        myg[lane] = dctx[(row0 + i) * H + h * 64 + lane];
+        __builtin_amdgcn_wave_barrier();
+        float dp[TXT_LONG_CH], pv[TXT_LONG_CH];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < TXT_LONG_CH; c++) {
+            const int j = lane + c * 64;
+            float acc = 0.f;
+            pv[c] = 0.f;
+            if (j < L) {
+                for (int d = 0; d < 64; d++) acc += myg[d] * st[j * 65 + d];
+                pv[c] = P[(size_t)i * L + j];
+            }
+            dp[c] = acc;
+            dot += acc * pv[c];
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int c = 0; c < TXT_LONG_CH; c++) {
+            const int j = lane + c * 64;
+            if (j < L) dS[(size_t)i * L + j] = pv[c] * (dp[c] - dot);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // phase A2 (keys staged): dq_i = dS_i . k / 8 (a lane reads back the dS entries it wrote)
+    stage_rows65(st, qkv + row0 * 3 * H + H + h * 64, (size_t)3 * H, L, tid);
+    __syncthreads();
+    for (int i = wave; i < L; i += 4) {
+        for (int j = lane; j < L; j += 64) myp[j] = dS[(size_t)i * L + j];
+        __builtin_amdgcn_wave_barrier();
+        float o = 0.f;
+        for (int j = 0; j < L; j++) o += myp[j] * st[j * 65 + lane];
+        dqkv[(row0 + i) * 3 * H + h * 64 + lane] = from_f32<T>(o * 0.125f);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __threadfence_block();                               // dS rows of all waves visible to all waves below
+    __syncthreads();
+    // phase B1 (queries staged): dk_j = dS^T q / 8
+    stage_rows65(st, qkv + row0 * 3 * H + h * 64, (size_t)3 * H, L, tid);
+    __syncthreads();
+    for (int j = wave; j < L; j += 4) {
+        float dk = 0.f;
+        for (int i = 0; i < L; i++) dk += dS[(size_t)i * L + j] * st[i * 65 + lane];
+        dqkv[(row0 + j) * 3 * H + H + h * 64 + lane] = from_f32<T>(dk * 0.125f);
+    }
+    __syncthreads();
+    // phase B2 (dctx staged): dv_j = P^T dctx
+    stage_rows65(st, dctx + row0 * H + h * 64, (size_t)H, L, tid);
+    __syncthreads();
+    for (int j = wave; j < L; j += 4) {
+        float dv = 0.f;
+        for (int i = 0; i < L; i++) dv += P[(size_t)i * L + j] * st[i * 65 + lane];
         dqkv[(row0 + j) * 3 * H + 2 * H + h * 64 + lane] = from_f32<T>(dv);
     }
 }
@@ -494,26 +652,45 @@ int text_embed(const int64_t* ids, int ld_ids, const float* word, const float* p
 }
 
 static size_t self_attn_smem(int L, int nw = 4) { return (size_t)(2 * L * 65 + (nw + 1) * TXT_MAX_L + nw * 64) * sizeof(float); }
+static size_t self_attn_long_smem(int L) { return (size_t)(L * 65 + 5 * TXT_LONG_L + 4 * 64) * sizeof(float); }
 
-int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, void* ctx, float* probs, int B, int L,
+// one-time per device: the kernels' opt-in to more than 64 KB of dynamic LDS (common.h: lds_opt_in)
+#define PNP_OPT_IN(kernel, bytes)                                                               \
+    do {                                                                                        \
+        static std::atomic<uint32_t> opted{0};                                                  \
+        if (lds_opt_in(opted, reinterpret_cast<const void*>(kernel), (int)(bytes)) != PNP_OK) return PNP_ERR_HIP; \
+    } while (0)
+
+int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, void* ctx, float* probs, float* scratch, int B, int L,
                    int H, hipStream_t s) {
-    if (L > TXT_MAX_L || H % 64) return PNP_ERR_ARG;
-    const size_t smem = self_attn_smem(L);
+    if (L > TXT_LONG_L || H % 64) return PNP_ERR_ARG;
     dim3 grid(H / 64, B);
+    if (L > TXT_MAX_L) {
+        // long captions: the probabilities of a row pass through global memory (the stash, else `scratch`: [B, heads, L, L])
+        float* pg = probs ? probs : scratch;
+        if (!pg) return PNP_ERR_ARG;
+        const size_t smem = self_attn_long_smem(L);
+        if (bf) {
+            PNP_OPT_IN(text_self_attn_long_kernel<bf16>, self_attn_long_smem(TXT_LONG_L));
+            hipLaunchKernelGGL((text_self_attn_long_kernel<bf16>), grid, dim3(256), smem, s, (const bf16*)qkv, mask, ld_mask, (bf16*)ctx, pg, L, H);
+        } else {
+            PNP_OPT_IN(text_self_attn_long_kernel<float>, self_attn_long_smem(TXT_LONG_L));
+            hipLaunchKernelGGL((text_self_attn_long_kernel<float>), grid, dim3(256), smem, s, (const float*)qkv, mask, ld_mask, (float*)ctx, pg, L, H);
+        }
+        return ok();
+    }
+    const size_t smem = self_attn_smem(L);
     if (bf) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(text_self_attn_kernel<bf16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)self_attn_smem(TXT_MAX_L));
+        PNP_OPT_IN(text_self_attn_kernel<bf16>, self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_kernel<bf16>), grid, dim3(256), smem, s, (const bf16*)qkv, mask, ld_mask,
                            (bf16*)ctx, probs, L, H);
     } else if (L <= 64) {
         // short captions (one wave per query row, L / waves rows each): 8 waves per (image, head)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(text_self_attn_kernel<float, 8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)self_attn_smem(64, 8));
+        PNP_OPT_IN((text_self_attn_kernel<float, 8>), self_attn_smem(64, 8));
         hipLaunchKernelGGL((text_self_attn_kernel<float, 8>), grid, dim3(512), self_attn_smem(L, 8), s, (const float*)qkv, mask, ld_mask,
                            (float*)ctx, probs, L, H);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(text_self_attn_kernel<float>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)self_attn_smem(TXT_MAX_L));
+        PNP_OPT_IN(text_self_attn_kernel<float>, self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_kernel<float>), grid, dim3(256), smem, s, (const float*)qkv, mask, ld_mask,
                            (float*)ctx, probs, L, H);
     }
@@ -522,22 +699,32 @@ int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, vo
 
 int text_self_attn_bwd(int bf, const void* qkv, const float* dctx, const float* probs, float* ds_scratch, void* dqkv,
                        int B, int L, int H, hipStream_t s) {
-    if (L > TXT_MAX_L || H % 64) return PNP_ERR_ARG;
-    const size_t smem = self_attn_smem(L);
+    if (L > TXT_LONG_L || H % 64) return PNP_ERR_ARG;
     dim3 grid(H / 64, B);
+    if (L > TXT_MAX_L) {
+        const size_t smem = self_attn_long_smem(L);
+        if (bf) {
+            PNP_OPT_IN(text_self_attn_bwd_long_kernel<bf16>, self_attn_long_smem(TXT_LONG_L));
+            hipLaunchKernelGGL((text_self_attn_bwd_long_kernel<bf16>), grid, dim3(256), smem, s, (const bf16*)qkv, dctx, probs, ds_scratch, (bf16*)dqkv, L, H);
+        } else {
+            PNP_OPT_IN(text_self_attn_bwd_long_kernel<float>, self_attn_long_smem(TXT_LONG_L));
+            hipLaunchKernelGGL((text_self_attn_bwd_long_kernel<float>), grid, dim3(256), smem, s, (const float*)qkv, dctx, probs, ds_scratch, (float*)dqkv, L, H);
+        }
+        return ok();
+    }
+    const size_t smem = self_attn_smem(L);
     if (bf) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(text_self_attn_bwd_kernel<bf16>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)self_attn_smem(TXT_MAX_L));
+        PNP_OPT_IN(text_self_attn_bwd_kernel<bf16>, self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_bwd_kernel<bf16>), grid, dim3(256), smem, s, (const bf16*)qkv, dctx, probs,
                            ds_scratch, (bf16*)dqkv, L, H);
     } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(text_self_attn_bwd_kernel<float>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)self_attn_smem(TXT_MAX_L));
+        PNP_OPT_IN(text_self_attn_bwd_kernel<float>, self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_bwd_kernel<float>), grid, dim3(256), smem, s, (const float*)qkv, dctx, probs,
                            ds_scratch, (float*)dqkv, L, H);
     }
     return ok();
 }
+#undef PNP_OPT_IN
 
 template <typename T, int MODE>
 static int xattn_launch(const void* a1, int ld1, const void* a2t, int ld2, int Npad, const void* x, int ldx, void* out,

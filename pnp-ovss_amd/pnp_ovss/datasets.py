@@ -101,7 +101,8 @@ class _Base:
         """Items whose first element is None get their model tensor from the device-side resize + normalise
         (hip.preprocess_images: Pillow-exact, Dataset.py:434-443 / :1263) over the decoded RGB the CRF uses anyway."""
         if torch.cuda.is_available():
-            torch.cuda.set_device(self.rank)                     # this generator may run in a prefetch thread (rank = device)
+            # this generator may run in a prefetch thread; device = rank unless the driver says otherwise (--share_gpu)
+            torch.cuda.set_device(int(getattr(self.args, "device_index", self.rank)))
         idx = self._indices(len(self))
         # JPEG / PNG decode of a batch on a small thread pool (Pillow releases the GIL while decoding): at ~300 images/s
         # per GPU one decoding thread (2-4 ms per VOC-sized image) would be the bottleneck (the reference decodes on the
@@ -272,6 +273,7 @@ class CocoDataset(_Base):
             with open(f"{home}/coco/annotations/stuff_val2017.json") as f:
                 cats += [{"id": c["id"], "name": c["name"]} for c in json.load(f)["categories"]]
             self.max_channels = 184
+            self.max_text_len = 320          # 171 class names with their word-piece splits (the text kernels take up to 512 tokens)
         self.kind = kind
         self.rank, self.world, self.args = rank, world_size, args
         self.cats = cats                                          # list of dicts, like the reference's `cats`

@@ -49,6 +49,7 @@ def load_library():
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     sig = {
         "pnp_create": (i32, [C.POINTER(PnpConfig), C.POINTER(vp)]),
+        "pnp_create_shared": (i32, [C.POINTER(PnpConfig), vp, C.POINTER(vp)]),
         "pnp_destroy": (None, [vp]),
         "pnp_last_error": (C.c_char_p, [vp]),
         "pnp_workspace_bytes": (C.c_size_t, [C.POINTER(PnpConfig)]),
@@ -104,7 +105,7 @@ def load_library():
     return lib
 
 
-EXPORTED = ["pnp_create", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes", "pnp_load_weight",
+EXPORTED = ["pnp_create", "pnp_create_shared", "pnp_destroy", "pnp_last_error", "pnp_workspace_bytes", "pnp_load_weight",
             "pnp_finalize_weights", "pnp_vit_forward", "pnp_text_forward_xattn", "pnp_xattn_grad",
             "pnp_gradcam_gather", "pnp_compute_gradcam", "pnp_drop_step", "pnp_drop_loop", "pnp_post_reserve",
             "pnp_post_prepare", "pnp_merge_tokens", "pnp_threshold_upsample", "pnp_blur_minmax", "pnp_densecrf",
@@ -277,10 +278,11 @@ class Engine:
 
     MODES = {"f32": 0, "bf16": 1, "bf16x3": 2}
 
-    def __init__(self, cfg, max_batch, max_text_len=64, stash_layer=7, bf16=False, device=0, mode=None):
+    def __init__(self, cfg, max_batch, max_text_len=64, stash_layer=7, bf16=False, device=0, mode=None, share_weights_with=None):
         """mode: "f32" (the reference's arithmetic; the default), "bf16x3" (split-bf16: fp32-class results on the bf16
         MFMA), "bf16" (throughput; does not reproduce the reference's patch picks); `bf16=True/False` is the older
-        spelling of "bf16" / "f32"."""
+        spelling of "bf16" / "f32".  share_weights_with: a finalized Engine of the same geometry, device and mode whose
+        weights this one uses (pnp_create_shared: activations and workspace of its own, no load_state_dict)."""
         if not torch.cuda.is_available():
             raise RuntimeError("pnp_ovss.hip.Engine needs a HIP device (no CPU fallback)")
         self.lib = load_library()
@@ -300,10 +302,17 @@ class Engine:
         self._c = c
         self.h = C.c_void_p()
         torch.cuda.set_device(device)
-        r = self.lib.pnp_create(C.byref(c), C.byref(self.h))
+        if share_weights_with is not None:
+            r = self.lib.pnp_create_shared(C.byref(c), share_weights_with.h, C.byref(self.h))
+        else:
+            r = self.lib.pnp_create(C.byref(c), C.byref(self.h))
         if r != 0:
             msg = self.lib.pnp_last_error(self.h).decode() if self.h else "?"
-            raise RuntimeError(f"pnp_create failed ({r}): {msg}")
+            if self.h:
+                self.lib.pnp_destroy(self.h)
+                self.h = C.c_void_p()
+            raise RuntimeError(f"pnp_create{'_shared' if share_weights_with is not None else ''} failed ({r}): {msg}")
+        self.shares_weights = share_weights_with is not None
         self._keep = []
 
     # ------------------------------------------------------------------ plumbing

@@ -53,7 +53,8 @@ class _Obj:
     pass
 
 
-MAX_TEXT_TOKENS = 192        # longest caption the text kernels take (csrc/text_kernels.hip TXT_MAX_L; pnp_create rejects more)
+MAX_TEXT_TOKENS = 512        # longest caption the text kernels take (csrc/text_kernels.hip TXT_LONG_L = BERT's max_position_embeddings;
+                             # the reference tokenises to max_length = 500, PnP.py:271,318)
 
 
 class BlipITM(torch.nn.Module):
@@ -117,10 +118,10 @@ class BlipITM(torch.nn.Module):
         """Create (or, for a lazily built model, re-create) the engine so that it fits the call at hand.  Eager models
         only check and fail loudly, as before."""
         if text_len is not None and text_len > MAX_TEXT_TOKENS:
-            # before anything is torn down: no engine can serve the call (the reference's tokenizer allows max_length = 500;
-            # the longest caption of the four datasets, ADE20K's 150 class names, is 155 tokens)
-            raise RuntimeError(f"caption of {text_len} tokens: the HIP text kernels take at most {MAX_TEXT_TOKENS} "
-                               f"(150-class prompts are 155); split the class list")
+            # before anything is torn down: no engine can serve the call (BERT's position table ends at 512; the reference's
+            # tokenizer truncates at max_length = 500)
+            raise RuntimeError(f"caption of {text_len} tokens: the text stack takes at most {MAX_TEXT_TOKENS} "
+                               f"(max_position_embeddings)")
         eng = self._engine
         if eng is not None:
             fits = ((img_size is None or img_size == eng.cfg.img_size) and (batch is None or batch <= eng.max_batch) and
@@ -342,14 +343,34 @@ def _model_config(model_type, img_size):
     return C.blip_itm_large(int(img_size or 336)), seed            # image_size: 336 (blip_itm_large.yaml:17)
 
 
+def weights_digest(flat):
+    """Two order-independent 64-bit integer sums over the bit patterns of a flat fp32 weight buffer (device or host): equal
+    buffers give equal digests on every rank, and the sums are exact (wrap-around int64), so ranks compare them with ==."""
+    bits = flat.view(torch.int32)
+    s0 = torch.zeros((), dtype=torch.int64, device=flat.device)
+    s1 = torch.zeros((), dtype=torch.int64, device=flat.device)
+    step = 1 << 26
+    for o in range(0, bits.numel(), step):
+        b = bits[o:o + step].to(torch.int64)
+        s0 += b.sum()
+        s1 += (b * (torch.arange(o, o + b.numel(), device=flat.device, dtype=torch.int64) % 65521 + 1)).sum()
+    return torch.stack([s0, s1])
+
+
 def build_model(model_type="large", img_size=None, device=0, max_batch=None, max_text_len=None, stash_layer=None, bf16=None,
-                checkpoint=None, vocab=None, seed=None, cfg=None, mode=None):
+                checkpoint=None, vocab=None, seed=None, cfg=None, mode=None, sync=None, receive_only=False, donor=None):
     """from_config + load_checkpoint (blip_image_text_matching.py:297-314, base_model.py:86-125).
 
     With the engine's sizing given (img_size or cfg, max_batch, stash_layer) the engine is created here.  Without -- the
     reference's own call, PnP.py:1212 -- the model is lazy (see BlipITM): weights are loaded into device buffers now, the
     engine follows the first call.  Compute mode: `mode` ("f32" | "bf16x3" | "bf16"), else PNP_OVSS_DTYPE, else "f32" --
-    the reference's arithmetic; "bf16" is never a default."""
+    the reference's arithmetic; "bf16" is never a default.
+
+    Multi-rank (eager models): `sync(flat)` is called with every weight of the path in one flat fp32 DEVICE buffer before
+    the engine takes them -- the driver broadcasts rank 0's buffer over RCCL there and / or checks a digest across ranks
+    (the construction-time broadcast of the reference's DDP wrapper, PnP.py:1218); `receive_only` ranks skip the checkpoint
+    and the initialisation and only receive.  `donor`: another model of the same geometry, device and mode whose engine
+    lends its (converted, read-only) weights: the new engine allocates activations and workspace only (--pipelines)."""
     cfg_seed = None
     if cfg is None:
         cfg, cfg_seed = _model_config(model_type, img_size)
@@ -361,8 +382,30 @@ def build_model(model_type="large", img_size=None, device=0, max_batch=None, max
     vocab = vocab or os.environ.get("PNP_OVSS_VOCAB")
     dev = device if isinstance(device, int) else (torch.device(device).index or 0)
     tok = WordPieceTokenizer(vocab) if vocab else SynthTokenizer(cfg.vocab)
-    init = synth.synth_state_dict(cfg, seed)                      # stands in for the module's initialisation
     eager = max_batch is not None and stash_layer is not None
+    if donor is not None:
+        if not eager:
+            raise ValueError("donor= needs an eager model (max_batch and stash_layer given)")
+        d = donor.module if hasattr(donor, "module") else donor
+        eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len or 64, stash_layer=stash_layer, device=dev, mode=mode,
+                     share_weights_with=d.engine)
+        return BlipITM(cfg, eng, tok)
+    if receive_only:
+        if not (eager and sync is not None):
+            raise ValueError("receive_only needs an eager model and a sync callable that fills the weights")
+        shapes = synth.param_shapes(cfg)
+        torch.cuda.set_device(dev)
+        flat = torch.empty(sum(int(np.prod(s)) for s in shapes.values()), dtype=torch.float32, device=torch.device("cuda", dev))
+        sync(flat)
+        eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len or 64, stash_layer=stash_layer, device=dev, mode=mode)
+        sd, o = {}, 0
+        for n, shp in shapes.items():
+            k = int(np.prod(shp))
+            sd[n] = flat[o:o + k].view(*shp)
+            o += k
+        eng.load_state_dict(sd)
+        return BlipITM(cfg, eng, tok)
+    init = synth.synth_state_dict(cfg, seed)                      # stands in for the module's initialisation
     if checkpoint:
         sd = torch.load(checkpoint, map_location="cpu")
         sd = sd["model"] if "model" in sd else sd
@@ -375,6 +418,20 @@ def build_model(model_type="large", img_size=None, device=0, max_batch=None, max
         warnings.warn("no BLIP checkpoint given (PNP_OVSS_CHECKPOINT): using seeded synthetic weights")
         state, raw_pos = init, None
     if eager:
+        if sync is not None:
+            # one flat device buffer in param_shapes order (what receive_only ranks allocate): the driver's collective runs on it
+            shapes = synth.param_shapes(cfg)
+            torch.cuda.set_device(dev)
+            flat = torch.empty(sum(int(np.prod(s)) for s in shapes.values()), dtype=torch.float32, device=torch.device("cuda", dev))
+            o, sd = 0, {}
+            for n, shp in shapes.items():
+                k = int(np.prod(shp))
+                t = state[n]
+                flat[o:o + k].copy_(torch.as_tensor(np.asarray(t) if not isinstance(t, torch.Tensor) else t, dtype=torch.float32).reshape(-1))
+                sd[n] = flat[o:o + k].view(*shp)
+                o += k
+            sync(flat)
+            state = sd
         eng = Engine(cfg, max_batch=max_batch, max_text_len=max_text_len or 64, stash_layer=stash_layer, device=dev, mode=mode)
         eng.load_state_dict(state)
         return BlipITM(cfg, eng, tok)

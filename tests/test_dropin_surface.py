@@ -420,3 +420,50 @@ def test_validate_real_kit_self_test(tmp_path):
     assert abs(rep["miou"]["f32"]["n_drop"]["Mean IoU"] - rep["miou"]["bf16x3"]["n_drop"]["Mean IoU"]) < 1e-3
     z = np.load(out / "maps.npz")
     assert z["map_7_9_f32"].shape == z["map_7_9_bf16x3"].shape and z["map_7_9_f32"].shape[0] == 3
+
+
+def test_cli_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
+    """The CLI's multi-rank path (VERDICT r04 task 5) under its own `--world_size 2` spawn on the one GPU a test box has
+    (`--share_gpu --backend gloo`; RCCL refuses two ranks on one device): rank 1 loads nothing and receives rank 0's weights
+    in the start-up broadcast (PnP.py:1218), the digests are compared, the image count and the confusion matrix are
+    all-reduced (PnP.py:513-520 -> Calculate_mIoU.py:215-219 in the reference), the label maps are gathered on rank 0.
+    A 12-image VOC-layout tree of JPEG files, one image per batch (the reference's results depend on what else is in a
+    batch -- the longest caption sets L, PnP.py:639 -- so one image per batch makes the sharding invisible): the summed
+    histogram, the per-batch .npy files and every gathered label map must equal the one-rank run's."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import cli_e2e
+    home = tmp_path / "home"
+    home.mkdir()
+    cli_e2e.build_tree(home, 12, seed=3)
+    runs = {}
+    for W in (1, 2):
+        save = tmp_path / f"out{W}"
+        cmd = [sys.executable, os.path.join(ROOT, "pnp-ovss_amd", "PnP_OVSS_0514_updated_segmentation.py"),
+               "--home_dir", str(home), "--save_path", str(save), "--world_size", str(W), "--img_size", "336", "--del_patch_num",
+               "sort_thresh005", "--batch_size", "1", "--max_att_block_num", "8", "--drop_iter", "4", "--prune_att_head", "9",
+               "--sort_threshold", "0.05", "--threshold", "0.15", "--postprocess", "blur+crf", "--data_type", "voc",
+               "--dtype", "bf16x3", "--gather_labels", "--master_port", "29611"]
+        if W > 1:
+            cmd += ["--share_gpu", "--backend", "gloo"]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+            env.pop(k, None)
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        files = {}
+        for d in ("hist_withfiltered_caption", "all_drop_hist_with_filtered_caption"):
+            for f in sorted(glob.glob(str(save / d / "*.npy"))):
+                files[d + "/" + os.path.basename(f)] = np.load(f)
+        runs[W] = (line, files, dict(np.load(save / "label_maps.npz")), out.stdout)
+    (l1, f1, m1, _), (l2, f2, m2, o2) = runs[1], runs[2]
+    assert l1["images"] == l2["images"] == 12 and l2["ranks"] == 2 and l2["images_rank0"] == 6
+    assert l2["weights_sync"]["mode"] == "broadcast" and l2["weights_sync"]["bytes"] > 1.7e9 and "digests equal" in o2
+    assert l2["gathered_label_maps"]["images"] == 12 and len(l2["gathered_label_maps"]["bytes_per_rank"]) == 2
+    assert l1["pixels"] == l2["pixels"] and l1["Mean IoU"] == l2["Mean IoU"] and l1["Pixel Accuracy"] == l2["Pixel Accuracy"]
+    assert len(f1) == 24 and sorted(f1) == sorted(f2)
+    for k in f1:
+        np.testing.assert_array_equal(f1[k], f2[k])
+    assert sorted(m1) == sorted(m2) and len(m1) == 12
+    for k in m1:
+        np.testing.assert_array_equal(m1[k], m2[k])

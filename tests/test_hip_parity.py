@@ -811,7 +811,10 @@ def test_engines_in_flight_match_one_at_a_time():
     """bench.py --pipelines / the CLI keep several batches in flight per GPU: distinct engines, each driven from its own host
     thread on its own HIP stream (include/pnp_hip.h: distinct handles are independent).  Three engines running the whole
     path concurrently -- drop loop, lattice build, paired blur + CRF, histogram -- must reproduce, bit for bit, what one of
-    them produces alone (different seeds per engine input so that a cross-talk between workspaces would show)."""
+    them produces alone (different seeds per engine input so that a cross-talk between workspaces would show).
+    Round 5: engines 1 and 2 are created ON ENGINE 0's WEIGHTS (pnp_create_shared, what bench.py / --pipelines run): they
+    must equal an engine that loaded its own copy, hold no weight bytes of their own, refuse load_state_dict, and keep
+    working after the donor is destroyed (shared ownership of the weight store)."""
     import threading
     from pnp_ovss.hip import Engine
     g = _golden("droploop_small.npz")
@@ -824,8 +827,13 @@ def test_engines_in_flight_match_one_at_a_time():
     S = cfg.img_size
     engines, inputs = [], []
     for p in range(P):
-        e = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, mode="f32")
-        e.load_state_dict(sd)
+        e = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, mode="f32", share_weights_with=engines[0] if p else None)
+        if p == 0:
+            e.load_state_dict(sd)
+        else:
+            assert e.shares_weights and e.allocated_bytes() < engines[0].allocated_bytes()
+            with pytest.raises(RuntimeError):
+                e.load_state_dict({"itm_head.bias": sd["itm_head.bias"]}, finalize=False)
         e.post_reserve(B, B * S * S, S * S, K + 1, 0)
         engines.append(e)
         rgb, imgs = synth.synth_images(B, S, seed=100 + p)
@@ -868,6 +876,25 @@ def test_engines_in_flight_match_one_at_a_time():
     for p in range(P):
         for a, b in zip(alone[p], together[p]):
             np.testing.assert_array_equal(a, b)
+    # an engine with its OWN weight copy gives what the sharing engine 1 gave
+    own = Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, mode="f32")
+    own.load_state_dict(sd)
+    own.post_reserve(B, B * S * S, S * S, K + 1, 0)
+    engines.append(own)
+    inputs.append(inputs[1])
+    for a, b in zip(alone[1], whole_path(P, 1)):
+        np.testing.assert_array_equal(a, b)
+    # geometry / mode / layer range must match the donor's
+    with pytest.raises(RuntimeError):
+        Engine(cfg, max_batch=B, max_text_len=32, stash_layer=7, mode="bf16x3", share_weights_with=engines[0])
+    with pytest.raises(RuntimeError):
+        Engine(cfg, max_batch=B, max_text_len=32, stash_layer=5, mode="f32", share_weights_with=engines[0])
+    # the weights outlive the donor
+    engines[0].close()
+    for a, b in zip(alone[2], whole_path(2, 1)):
+        np.testing.assert_array_equal(a, b)
+    for e in engines[1:]:
+        e.close()
     assert any((alone[0][3] != alone[1][3]).ravel())          # the engines really worked on different images
     for e in engines:
         e.close()
@@ -995,6 +1022,12 @@ def test_whole_path_full_size_properties_per_config(name, img, n_cls, data_type,
 # four fixtures on MI355X (f32: 1.3e-5, bf16x3: 1.9e-4 -- the size of each mode's normalised-map error), and the number of
 # flipped pixels is bounded as well (measured: at most 148 of 34 684, all in one no-post-process output of pipeline_psc).
 E2E_TIE = {"f32": 3e-5, "bf16x3": 4e-4}
+# the same rule at the HEADLINE geometry (pipeline_voc_large.npz: BLIP-ITM-large 336^2, 24 ViT blocks instead of 2): the maps of
+# both modes sit further from the reference's (normalised-map error 2.2e-4 / 3.0e-4 in test_drop_loop_large_vs_reference_golden
+# against 5e-5 / 1.2e-4 at small geometry), so near-ties are wider; measured on MI355X below, bound = ~2x the measured gap
+# (f32: 8 / 185 / 7 / 0 flipped pixels of 300 396 on 1-drop blur / 1-drop none / N-drop blur / N-drop none, largest gap 1.73e-4;
+#  bf16x3: 7 / 225 / 15 / 0, largest gap 1.21e-3 -- the 185 / 225 are exact ties of Scale_0_1 maps, gap ~1e-7)
+E2E_TIE_LARGE = {"f32": 3.5e-4, "bf16x3": 2.5e-3}
 
 @pytest.mark.parametrize("mode_", ["f32", "bf16x3"])
 @pytest.mark.parametrize("fname", ["pipeline_voc.npz", "pipeline_psc.npz", "pipeline_voc_large.npz"])
@@ -1063,7 +1096,7 @@ def test_end_to_end_labels_vs_reference_run(fname, mode_):
                     rel = (srt[-1] - srt[-2]) / np.maximum(np.abs(srt[-1]), 1e-30)
                     if diff.any():
                         gap = max(gap, float(rel[diff].max()))
-                    diff &= ~(rel <= E2E_TIE[mode_])
+                    diff &= ~(rel <= (E2E_TIE_LARGE if large else E2E_TIE)[mode_])
                 bad += int(diff.sum())
             print(f"[e2e {fname} {mode_} {name} {mode}] label pixels differing from the reference's: {flips} of {total}, "
                   f"largest relative gap between the two best channels at such a pixel {gap:.2e}")
@@ -1265,18 +1298,20 @@ def test_bf16x3_picks_equal_f32_at_blip_large_batch35():
     assert differ < 5e-3, differ
 
 
-@pytest.mark.parametrize("n_classes", [150, 187])
+@pytest.mark.parametrize("n_classes", [150, 187, 295, 495])
 def test_gradcam_long_caption_vs_oracle(n_classes):
-    """Text path above 64 tokens: an ADE20K-sized caption (150 classes, L = 155) and the longest the engine takes (L = 192)
-    through the text self-attention / cross-attention / backward kernels, small geometry, against the oracle."""
+    """Text path above 64 tokens: an ADE20K-sized caption (150 classes, L = 155), the longest the one-phase self-attention
+    kernels take (L = 192) and -- round 5 -- captions beyond it through the phased long-caption kernels: L = 300 and the
+    reference's own limit L = 500 (`max_length=500`, PnP.py:271,318; BERT's position table ends at 512), through the text
+    self-attention / cross-attention / backward kernels, small geometry, against the oracle."""
     cfg = C.blip_itm_small(128)
     W = synth.synth_state_dict(cfg, 4)
     _, imgs = synth.synth_images(2, cfg.img_size, seed=9)
     ids, mask = synth.synth_tokens(cfg, [n_classes, 7], seed=9)
     L = int(mask.sum(1).max())
-    assert L == n_classes + 5 and L <= 192
+    assert L == n_classes + 5 and L <= 500
     for mode in ("f32", "bf16x3"):
-        e = _engine(cfg, 4, mode, max_batch=2, max_text_len=192)
+        e = _engine(cfg, 4, mode, max_batch=2, max_text_len=192 if L <= 192 else 512)
         out, logits = e.compute_gradcam(_dev(imgs), _dev(ids), _dev(mask), L, 9)
         torch.cuda.synchronize()
         maps, ref_logits, _ = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7])
@@ -1686,9 +1721,9 @@ def test_merge_tokens_kernel_on_real_tokenizer_splits():
     from pnp_ovss.hip import Engine
     cfg = C.blip_itm_small(128)
     _ENG.clear()
-    cases = [c for c in wordpiece_merge_cases() if len(c[1]) + 5 <= 192]       # captions the text kernels take (L <= 192)
-    assert len(cases) >= 7
-    e = Engine(cfg, max_batch=len(cases), max_text_len=192, stash_layer=7, mode="f32")
+    cases = [c for c in wordpiece_merge_cases() if len(c[1]) + 5 <= 500]       # captions the reference's tokenizer keeps whole
+    assert len(cases) >= 7 and max(len(c[1]) for c in cases) >= 245
+    e = Engine(cfg, max_batch=len(cases), max_text_len=256, stash_layer=7, mode="f32")
     Cmax = max(len(c[2]) for c in cases)
     S = 32
     e.post_reserve(len(cases), len(cases) * S * S, S * S, Cmax + 1, 0)

@@ -17,13 +17,14 @@ Candidates (cost in bf16-MFMA equivalents per product; int8 MFMAs run at twice t
   i8_3x2_5      2.5  3 activation slices x 2 weight slices, the five products with i + j <= 2 ... (2,1) dropped
   i8_3x3_6      3.0  3 x 3 slices, i + j <= 2: the int8 form with no saving (calibration row)
   h<...>             the same after an orthonormal Hadamard rotation of both operands along K (spreads outlier channels)
-Weights: the seeded synthetic state dict, optionally with OUTLIER channels injected (--outliers): a handful of LayerNorm gains
-x30, fc1 rows x8 and V rows x8 per block -- real ViT-L checkpoints carry such channels, seeded Gaussians do not.
+Weights: the seeded synthetic state dict, optionally with OUTLIER channels injected (--outliers GAIN) as a function-preserving
+re-parametrisation (inject_outliers) -- real ViT-L checkpoints carry such channels, seeded Gaussians do not.  `f64` is a
+calibration row: the same model with every product in float64.
 
 Runs on the GPU box through torch (fp64 GEMMs; seconds per candidate at B = 35) or on the CPU at small B (minutes per candidate).
 Test infrastructure: never imported by the product.
 
-usage: python tools/precision_matrix.py [--batch 35] [--outliers] [--cands x3,i8_2x2_3,...] [--families all|qkv,proj,...] [--out f.json]
+usage: python tools/precision_matrix.py [--batch 35] [--outliers 16] [--cands x3,i8_2x2_3,...] [--families all|qkv,proj,...] [--out f.json]
 """
 import argparse
 import json
@@ -97,7 +98,7 @@ def int_slices(x, p):
 _TERMS = {"2x2_3": (2, 2, [(0, 0), (0, 1), (1, 0)]), "2x2_4": (2, 2, [(0, 0), (0, 1), (1, 0), (1, 1)]),
           "3x2_5": (3, 2, [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]),
           "3x3_6": (3, 3, [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (0, 2)])}
-COST = {"f32": 16.0, "x3": 3.0, "x2w8": 2.0, "x2a8": 2.0, "i8_2x2_3": 1.5, "i8_2x2_4": 2.0, "i8_3x2_5": 2.5, "i8_3x3_6": 3.0}
+COST = {"f32": 16.0, "f64": None, "x3": 3.0, "x2w8": 2.0, "x2a8": 2.0, "i8_2x2_3": 1.5, "i8_2x2_4": 2.0, "i8_3x2_5": 2.5, "i8_3x3_6": 3.0}
 
 
 class Gemm:
@@ -121,6 +122,8 @@ class Gemm:
     def _mm(self, mode, a, w):
         if mode == "f32":
             return a @ w.T
+        if mode == "f64":
+            return (a.to(F64) @ w.to(F64).T).to(F32)
         if mode in ("x3", "x2w8", "x2a8"):
             ah, al = split(a)
             bh, bl = self._w(w, "split", lambda t: tuple(s.T.contiguous() for s in split(t)))
@@ -173,6 +176,8 @@ class Model:
         return y + self.W[bname]
 
     def att_mm(self, a, b):
+        if self.att_mode == "f64":
+            return (a.to(F64) @ b.to(F64)).to(F32)
         return a @ b if self.att_mode == "f32" else mm_x3(a, b)
 
     def vit(self, img):
@@ -182,7 +187,7 @@ class Model:
         dh, ps = D // H, cfg.patch
         x = img.reshape(B, 3, P, ps, P, ps).permute(0, 2, 4, 1, 3, 5).reshape(B, P * P, 3 * ps * ps)
         wp = W[v + "patch_embed.proj.weight"].reshape(D, -1)
-        x = (x @ wp.T if self.att_mode == "f32" else mm_x3(x, wp.T)) + W[v + "patch_embed.proj.bias"]
+        x = (x @ wp.T if self.att_mode in ("f32", "f64") else mm_x3(x, wp.T)) + W[v + "patch_embed.proj.bias"]
         x = torch.cat([W[v + "cls_token"].expand(B, 1, D), x], 1) + W[v + "pos_embed"][:, : P * P + 1]
         N = x.shape[1]
         scale = dh ** -0.5
@@ -299,27 +304,50 @@ def drop_loop(model, imgs, ids, mask, drop_iter, layer, head, grid, patch):
     return preds[0].cpu().numpy(), agg.cpu().numpy(), newp
 
 
-def inject_outliers(W, cfg, seed=99):
-    """Outlier channels of the kind trained ViT-L checkpoints carry: per block 6 LayerNorm gains x30 (inputs of qkv / fc1),
-    4 hidden units of fc1 x8 (inputs of fc2), 4 V columns x8 (inputs of proj); final norm 6 gains x30 (inputs of cross K/V)."""
+def inject_outliers(W, cfg, gain, seed=99, n=6):
+    """Outlier channels of the kind trained ViT-L checkpoints carry, as a FUNCTION-PRESERVING re-parametrisation: per ViT block
+    `n` channels of each LayerNorm (gain and bias) are scaled by `gain` and the matching input columns of the consuming Linear
+    (qkv / fc1) by 1 / gain; `n` value channels of qkv (rows + bias) by `gain` and the matching proj columns by 1 / gain; `n`
+    channels of the final LayerNorm by `gain` and the matching columns of all 12 cross-attention key / value projections by
+    1 / gain.  In exact arithmetic the model is unchanged; element-wise-relative arithmetic (fp32, split bf16) sees the same
+    relative errors; per-row-scaled integer slices lose log2(gain) bits on every other channel of the row.  (The GELU between
+    fc1 and fc2 does not commute with a scale, so fc2's input carries no injected outliers.)"""
     g = np.random.default_rng(seed)
-    W = dict(W)
+    W = {k: v for k, v in W.items()}
     D = cfg.vit_dim
+    gain = np.float32(gain)
     for i in range(cfg.vit_depth):
         b = f"visual_encoder.blocks.{i}."
-        for nm in ("norm1.weight", "norm2.weight"):
-            w = W[b + nm].copy()
-            w[g.choice(D, 6, replace=False)] *= 30.0
-            W[b + nm] = w
-        w = W[b + "mlp.fc1.weight"].copy()
-        w[g.choice(w.shape[0], 4, replace=False)] *= 8.0
-        W[b + "mlp.fc1.weight"] = w
+        for nm, cons in (("norm1", "attn.qkv.weight"), ("norm2", "mlp.fc1.weight")):
+            ch = g.choice(D, n, replace=False)
+            for part in (".weight", ".bias"):
+                w = W[b + nm + part].copy()
+                w[ch] *= gain
+                W[b + nm + part] = w
+            w = W[b + cons].copy()
+            w[:, ch] /= gain
+            W[b + cons] = w
+        ch = g.choice(D, n, replace=False)
         w = W[b + "attn.qkv.weight"].copy()
-        w[2 * D + g.choice(D, 4, replace=False)] *= 8.0
+        w[2 * D + ch] *= gain
         W[b + "attn.qkv.weight"] = w
-    w = W["visual_encoder.norm.weight"].copy()
-    w[g.choice(D, 6, replace=False)] *= 30.0
-    W["visual_encoder.norm.weight"] = w
+        w = W[b + "attn.qkv.bias"].copy()
+        w[2 * D + ch] *= gain
+        W[b + "attn.qkv.bias"] = w
+        w = W[b + "attn.proj.weight"].copy()
+        w[:, ch] /= gain
+        W[b + "attn.proj.weight"] = w
+    ch = g.choice(D, n, replace=False)
+    for part in (".weight", ".bias"):
+        w = W["visual_encoder.norm" + part].copy()
+        w[ch] *= gain
+        W["visual_encoder.norm" + part] = w
+    for i in range(cfg.txt_layers):
+        for kv in ("key", "value"):
+            nm = f"text_encoder.encoder.layer.{i}.crossattention.self.{kv}.weight"
+            w = W[nm].copy()
+            w[:, ch] /= gain
+            W[nm] = w
     return W
 
 
@@ -353,13 +381,15 @@ def pick_pairs(ref, got, B):
 def build_modes(cand, families):
     if cand == "f32":
         return {f: "f32" for f in FAMILIES}, "f32", "f32"
+    if cand == "f64":                 # calibration: how far is an fp32 run from a higher-precision run of the same model
+        return {f: "f64" for f in FAMILIES}, "f64", "f32"
     return {f: (cand if f in families else "x3") for f in FAMILIES}, "x3", "x3"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=35 if DEV == "cuda" else 2)
-    ap.add_argument("--outliers", action="store_true")
+    ap.add_argument("--outliers", type=float, default=0.0, help="gain of the injected outlier channels (0: none)")
     ap.add_argument("--cands", default="x3,x2w8,x2a8,i8_2x2_3,i8_2x2_4,i8_3x2_5,i8_3x3_6,hi8_2x2_3,hi8_2x2_4,hi8_3x2_5")
     ap.add_argument("--families", default="all", help="'all', 'each' (one family at a time), or a comma list")
     ap.add_argument("--no-fixture", action="store_true")
@@ -369,7 +399,7 @@ def main():
     cfg = C.blip_itm_large(336)
     W0 = synth.synth_state_dict(cfg, 0)
     if a.outliers:
-        W0 = inject_outliers(W0, cfg)
+        W0 = inject_outliers(W0, cfg, a.outliers)
     B = a.batch
     work = []
     if not a.no_fixture:
