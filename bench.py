@@ -385,7 +385,8 @@ def run_rank(a):
                     sd[n] = flat[o:o + k].view(*shp)
                     o += k
                 e.load_state_dict(sd)
-            e.post_reserve(self.B, self.B * self.img * self.img, self.img * self.img, self.K, self.chunk)
+            pb = self.B if self.B <= 64 else self.w["batch"]             # images per prepared post-process batch
+            e.post_reserve(pb, pb * self.img * self.img, self.img * self.img, self.K, self.chunk)
             self.engines.append(e)
             return e
 
@@ -408,6 +409,27 @@ def run_rank(a):
         def one_step(self, e, st, d_img, d_rgb, separate=False):
             """The whole path over one batch: drop loop -> prepare (lattices of the batch) -> post-process of the branch(es)."""
             g0, agg, _, _ = e.drop_loop(d_img, self.d_ids, self.d_mask, self.L, HEAD, DROP_ITER)
+            if self.B > 64:
+                # --batch above what one prepared post-process batch holds (64 images: the image index has 6 bits in the lattice
+                # keys): the model runs on all B images, the post-processing in groups of the config's batch (35)
+                G = self.w["batch"]
+                px = self.img * self.img
+                keep1, keepn = [], []
+                for a0 in range(0, self.B, G):
+                    a1 = min(a0 + G, self.B)
+                    e.post_prepare(self.sizes[a0:a1], self.plans[a0:a1], self.luts[a0:a1], [self.bg] * (a1 - a0),
+                                   rgb=d_rgb[a0 * px * 3: a1 * px * 3], gt=self.d_gt[a0 * px: a1 * px], want_crf=True)
+                    if self.skip_1drop:
+                        keepn.append(e.postprocess(agg[a0:a1], THRESH, self.w["scale01"][1], "blur+crf", self.nh, st["histn"]).clone())
+                    else:
+                        l1, ln = e.postprocess_pair(g0[a0:a1], agg[a0:a1], THRESH, self.nh, st["hist1"], st["histn"], self.w["scale01"])
+                        keep1.append(l1.clone())
+                        keepn.append(ln.clone())
+                st["ln"] = torch.cat(keepn)
+                if keep1:
+                    st["l1"] = torch.cat(keep1)
+                st["keep"] = (g0, agg)
+                return
             e.post_prepare(self.sizes, self.plans, self.luts, [self.bg] * self.B, rgb=d_rgb, gt=self.d_gt, want_crf=True)
             s01 = self.w["scale01"]
             if self.skip_1drop:
@@ -523,8 +545,9 @@ def run_rank(a):
             crf = e.profile_read_stage(1)
             e.profile_enable(False)
             dt = coll.max_time(dt, dev)
-            idb = e.buffer("crf_idbase_bilateral", torch.int32)[: self.B + 1].cpu().numpy()
-            ppp = float(idb[self.B] - idb[0]) / float(self.B * self.img * self.img)
+            pb = self.B if self.B <= 64 else (self.B - 1) % self.w["batch"] + 1          # images of the last prepared group
+            idb = e.buffer("crf_idbase_bilateral", torch.int32)[: pb + 1].cpu().numpy()
+            ppp = float(idb[pb] - idb[0]) / float(pb * self.img * self.img)
             return dt, state, gemm, crf, ppp
 
     def roofline_gemm(dtype, gemm):

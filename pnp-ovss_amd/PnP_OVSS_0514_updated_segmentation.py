@@ -117,7 +117,8 @@ def make_weights_sync(args, rank, world_size):
         dg = weights_digest(flat)
         every = [torch.zeros_like(dg) for _ in range(world_size)]
         dist.all_gather(every, dg)
-        torch.cuda.synchronize()
+        if flat.is_cuda:
+            torch.cuda.synchronize()
         info.update(mode=args.weights_sync, bytes=int(flat.numel()) * 4, ms=1e3 * (time.perf_counter() - t0),
                     digest=[int(v) for v in dg.cpu()])
         bad = [r for r, d in enumerate(every) if not torch.equal(d, every[0])]

@@ -467,3 +467,26 @@ def test_cli_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
     assert sorted(m1) == sorted(m2) and len(m1) == 12
     for k in m1:
         np.testing.assert_array_equal(m1[k], m2[k])
+
+
+def test_bench_under_the_drivers_launcher_with_rccl_world_1():
+    """The driver's literal multi-GPU launch form -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` -- at the N a one-GPU box allows, with the real backend
+    ("nccl" = RCCL): the rank initialises an RCCL process group and every collective of the path (weight broadcast, timing
+    max, confusion-matrix all-reduce, label gather, per-rank all-gather) goes through RCCL calls, so an API-level mistake
+    in the N > 1 path shows here and not first in the scaling job (PnP.py:45-54, :1218)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29623", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pipelines", "2",
+           "--no-cpu-baseline", "--no-other-modes", "--no-other-configs", "--no-noise12", "--no-fixture-check"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["n_ranks"] == 1 and line["gathered_label_maps"] == 1 and line["value"] > 0
+    col = line["collectives"]
+    assert col["weight_bytes"] > 1.7e9 and col["weight_broadcast_ms"] >= 0 and len(col["per_rank_images_per_sec"]) == 1
+    assert col["gathered_label_bytes"] == [35 * 336 * 336]
+    assert len(line["pipelines"]["engine_device_bytes"]) == 2
+    assert line["pipelines"]["engine_device_bytes"][1] < line["pipelines"]["engine_device_bytes"][0]     # the second engine holds no weights

@@ -129,6 +129,83 @@ def test_world_size_2_sharding_reduce_gather_over_gloo(tmp_path):
     assert res["bcast"] == [1.0] * 5
 
 
+_CLI_COLLECTIVES_WORKER = r'''
+import argparse, importlib.util, json, os, sys
+import numpy as np, torch, torch.distributed as dist
+root, save, mode = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, os.path.join(root, "pnp-ovss_amd"))
+spec = importlib.util.spec_from_file_location("pnp_cli", os.path.join(root, "pnp-ovss_amd", "PnP_OVSS_0514_updated_segmentation.py"))
+cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+args = argparse.Namespace(weights_sync="broadcast" if mode != "checksum_bad" else "checksum")
+sync, info = cli.make_weights_sync(args, rank, world)
+flat = torch.arange(1000, dtype=torch.float32) * (1.0 if rank == 0 else 3.0)     # rank 1 starts with other weights
+if mode == "checksum_bad":
+    try:
+        sync(flat)
+        print(json.dumps({"rank": rank, "raised": False}))
+    except SystemExit as ex:
+        print(json.dumps({"rank": rank, "raised": True, "msg": str(ex)[:80]}))
+    dist.destroy_process_group()
+    sys.exit(0)
+sync(flat)
+assert torch.equal(flat, torch.arange(1000, dtype=torch.float32)), "broadcast did not deliver rank 0's weights"
+kept = {f"img{rank}_{i}": torch.full((3 + rank, 4 + i), 10 * rank + i, dtype=torch.uint8) for i in range(2 + rank)}
+got = cli.gather_label_maps(kept, rank, world, torch.device("cpu"), save)
+if rank == 0:
+    z = dict(np.load(os.path.join(save, "label_maps.npz")))
+    print(json.dumps({"info": {k: info[k] for k in ("mode", "bytes")}, "gathered": got,
+                      "maps": {k: [list(v.shape), int(v.min()), int(v.max())] for k, v in z.items()}}))
+dist.destroy_process_group()
+'''
+
+
+def _run_cli_collectives(tmp_path, mode):
+    script = tmp_path / "cw.py"
+    script.write_text(_CLI_COLLECTIVES_WORKER)
+    port = 29500 + (os.getpid() + 31) % 2000
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT, str(tmp_path), mode],
+                          capture_output=True, text=True, timeout=300)
+
+
+def test_cli_weights_broadcast_and_label_gather_world_size_2_gloo(tmp_path):
+    """The CLI's own start-up and end-of-run collectives (PnP_OVSS_0514_updated_segmentation.py: make_weights_sync,
+    gather_label_maps) with two ranks over gloo on CPU tensors: rank 1's buffer is overwritten by rank 0's (the DDP-constructor
+    broadcast of PnP.py:1218), the digests agree afterwards, and rank 0 ends up with every rank's ragged label maps."""
+    out = _run_cli_collectives(tmp_path, "broadcast")
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["info"] == {"mode": "broadcast", "bytes": 4000}
+    assert res["gathered"] == {"images": 5, "bytes_per_rank": [3 * 4 + 3 * 5, 4 * 4 + 4 * 5 + 4 * 6]}
+    assert res["maps"] == {"img0_0": [[3, 4], 0, 0], "img0_1": [[3, 5], 1, 1], "img1_0": [[4, 4], 10, 10],
+                           "img1_1": [[4, 5], 11, 11], "img1_2": [[4, 6], 12, 12]}
+
+
+def test_cli_weights_digest_mismatch_stops_every_rank(tmp_path):
+    """`--weights_sync checksum` with ranks that loaded different weights: every rank raises (nobody runs on a replica that
+    differs from rank 0's)."""
+    out = _run_cli_collectives(tmp_path, "checksum_bad")
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and all(l["raised"] for l in lines), lines
+
+
+def test_weights_digest_sees_single_bit_flips_and_swaps():
+    import torch
+    from pnp_ovss.model import weights_digest
+    a = torch.randn(100_000, generator=torch.Generator().manual_seed(0))
+    b = a.clone()
+    assert torch.equal(weights_digest(a), weights_digest(b))
+    b.view(torch.int32)[77_777] ^= 1
+    assert not torch.equal(weights_digest(a), weights_digest(b))
+    c = a.clone()
+    c[[5, 6]] = c[[6, 5]]                                  # same multiset of values: only the position-weighted sum moves
+    d0, d1 = weights_digest(a), weights_digest(c)
+    assert d0[0] == d1[0] and d0[1] != d1[1]
+
+
 def _bench(*args, timeout=300):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
                           timeout=timeout, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})

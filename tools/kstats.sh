@@ -2,6 +2,9 @@
 # GPU box: per-kernel stats of a command under rocprofv3.   bash tools/kstats.sh tag <python script + args>
 export TMPDIR=/tmp
 R=$PWD; TAG=$1; shift
+SCRIPT=$1; shift
+case "$SCRIPT" in /*) ;; *) SCRIPT=$R/$SCRIPT ;; esac      # rocprofv3 runs from /tmp: the script path must be absolute
+set -- "$SCRIPT" "$@"
 cd /tmp; rm -rf /tmp/ks_$TAG
 rocprofv3 --kernel-trace --stats -d /tmp/ks_$TAG -o prof --output-format csv -- python3 "$@" > /tmp/ks_$TAG.log 2>&1
 f=$(find /tmp/ks_$TAG -name "*kernel_stats.csv" | head -1)

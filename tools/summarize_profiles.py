@@ -18,12 +18,16 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").replace("pnp::", "").split("(")[0][:80]
 
 
-def kernel_stats(sub, out):
+CFG_IMAGES = {"psc59": 35, "coco80": 35, "ade768": 8}
+
+
+def kernel_stats(sub, out, cfg=None):
     rows = list(csv.DictReader(open(os.path.join(G, f"{TAG}_{sub}", "prof_kernel_stats.csv"))))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    lines = [f"# rocprofv3 --kernel-trace --stats of `python3 bench.py {'--dtype bf16 ' if 'bf16' in sub else ''}--steps 2 --warmup 1 "
+    lines = [f"# rocprofv3 --kernel-trace --stats of `python3 bench.py {'--dtype bf16 ' if 'bf16' in sub else ''}"
+             f"{'--config ' + cfg + ' ' if cfg else ''}--steps 2 --warmup 1 "
              f"--pipelines 1 --no-cpu-baseline --no-other-modes --no-other-configs --no-noise12 --no-fixture-check` "
-             f"({'bf16 throughput mode' if 'bf16' in sub else 'headline mode bf16x3'}; 3 steps of 35 images in the trace)",
+             f"({'bf16 throughput mode' if 'bf16' in sub else 'headline mode bf16x3'}; 3 steps of {CFG_IMAGES.get(cfg, 35)} images in the trace)",
              "# kernel | calls | total ms | avg us | min us | max us | % of GPU time"]
     for r in rows:
         t = float(r["TotalDurationNs"])
@@ -92,6 +96,13 @@ def main():
                   open(os.path.join(P, f"{TAG}_crf_l2_hit.json"), "w"), indent=1)
     except FileNotFoundError:
         pass
+    for cfg in CFG_IMAGES:                              # BASELINE configs 3-5 (tools/collect_profiles_configs.sh)
+        if os.path.exists(os.path.join(G, f"{TAG}_trace_{cfg}")):
+            kernel_stats(f"trace_{cfg}", f"{TAG}_{cfg}_kernel_stats_summary.txt", cfg)
+        if os.path.exists(os.path.join(G, f"{TAG}_pmc_{cfg}_FETCH_SIZE")):
+            tc = traffic(f"pmc_{cfg}_FETCH_SIZE", f"pmc_{cfg}_WRITE_SIZE", f" -- config {cfg}, headline mode bf16x3, DenseCRF kernels")
+            json.dump({"note": tc["note"], "kernels": {k: v for k, v in tc["kernels"].items() if "crf_" in k}},
+                      open(os.path.join(P, f"{TAG}_{cfg}_crf_traffic.json"), "w"), indent=1)
     b = os.path.join(G, f"{TAG}_bench.json")
     if os.path.exists(b):
         open(os.path.join(P, f"{TAG}_bench.json"), "w").write(open(b).read())
