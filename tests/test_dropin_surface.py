@@ -16,6 +16,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_compute_gradcam_ensemble_surface_matches_reference_golden(golden_dir):
     from pnp_ovss import config as C, synth
     from pnp_ovss.model import build_model
@@ -442,7 +449,7 @@ def test_cli_two_ranks_on_one_gpu_equal_one_rank(tmp_path):
                "--home_dir", str(home), "--save_path", str(save), "--world_size", str(W), "--img_size", "336", "--del_patch_num",
                "sort_thresh005", "--batch_size", "1", "--max_att_block_num", "8", "--drop_iter", "4", "--prune_att_head", "9",
                "--sort_threshold", "0.05", "--threshold", "0.15", "--postprocess", "blur+crf", "--data_type", "voc",
-               "--dtype", "bf16x3", "--gather_labels", "--master_port", "29611"]
+               "--dtype", "bf16x3", "--gather_labels", "--master_port", str(_free_port())]
         if W > 1:
             cmd += ["--share_gpu", "--backend", "gloo"]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -476,7 +483,7 @@ def test_bench_under_the_drivers_launcher_with_rccl_world_1():
     max, confusion-matrix all-reduce, label gather, per-rank all-gather) goes through RCCL calls, so an API-level mistake
     in the N > 1 path shows here and not first in the scaling job (PnP.py:45-54, :1218)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29623", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pipelines", "2",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--pipelines", "2",
            "--no-cpu-baseline", "--no-other-modes", "--no-other-configs", "--no-noise12", "--no-fixture-check"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
