@@ -55,10 +55,13 @@ CONFIGS = {
                    pipelines=3,
                    what="COCO-Object-shaped (BASELINE config 4, one GPU's share): 336x336, batch 35, 80-class prompt (L=85, K=81), "
                         "COCO driver rules: N-drop branch only (drop_iter >= 3), Scale_0_1, category-id labels, 91-row histogram"),
-    "ade768": dict(img=768, classes=150, data_type="ade20k", hist=151, batch=8, skip_1drop=False, scale01=(True, False), crf_chunk=2,
+    # batch 7, not 8: 7 x 2305 = 16 135 token rows are 63.03 row tiles of the persistent 256 x 256 GEMM -- 64 x 4 / 12 / 16 tiles =
+    # exactly 1 / 3 / 4 rounds on 256 CUs -- where 8 x 2305 = 18 440 rows (72.03 -> 73 row tiles) pay 2 / 4 / 5 rounds for a last
+    # row tile of 8 rows (round 5, tools/ade_sweep.sh: GEMM 0.134 -> 0.163 of peak, 14.7 -> 15.1 images/s)
+    "ade768": dict(img=768, classes=150, data_type="ade20k", hist=151, batch=7, skip_1drop=False, scale01=(True, False), crf_chunk=1,
                    pipelines=2,
                    what="ADE20K-shaped (BASELINE config 5, one GPU's share): 768x768 (2305 image tokens, pos-embed grid 48x48), "
-                        "150-class prompt (L=155, K=150), blur radius 154, DenseCRF in 2-image launch groups"),
+                        "7 images per step, 150-class prompt (L=155, K=150), blur radius 154, DenseCRF one image per launch group"),
 }
 
 
@@ -584,8 +587,8 @@ def run_rank(a):
     def traffic_for(dtype):
         """HBM-side bytes per launch of the dense GEMM family from the committed rocprofv3 PMC passes (FETCH_SIZE /
         WRITE_SIZE cannot be read live; see profiles/*_gemm_traffic*.json)."""
-        names = {"bf16": ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"),
-                 "bf16x3": ("r04_gemm_traffic_bf16x3.json", "r03_gemm_traffic_bf16x3.json")}.get(dtype, ())
+        names = {"bf16": ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"),
+                 "bf16x3": ("r05_gemm_traffic_bf16x3.json", "r04_gemm_traffic_bf16x3.json", "r03_gemm_traffic_bf16x3.json")}.get(dtype, ())
         for tf in names:
             tf = os.path.join(ROOT, "profiles", tf)
             if os.path.exists(tf):
@@ -671,8 +674,9 @@ def run_rank(a):
             fl = selfcheck.fixture_label_flips(a.dtype, os.path.join(ROOT, "tests", "golden"), device=local)
             out["label_pixels_differing_from_reference_fixtures"] = {
                 "frac": fl["frac"], "differing": fl["differing"], "pixels": fl["pixels"], "per_fixture": fl["per_fixture"],
-                "what": "pipeline_voc.npz + pipeline_psc.npz: the reference's save_img_union_attention label maps (1-drop and N-drop, "
-                        "blur and none) vs this mode's, same inputs; differences sit at float near-ties of the two best channels"}
+                "what": "pipeline_voc.npz + pipeline_psc.npz (small geometry) + pipeline_voc_large.npz (the HEADLINE geometry: BLIP-ITM-large "
+                        "336^2, 20-class prompt): the reference's save_img_union_attention label maps (1-drop and N-drop, blur and none) "
+                        "vs this mode's, same inputs; differences sit at float near-ties of the two best channels"}
         if single and not a.no_noise12 and a.noise != NOISE_HARD:
             n2 = max(1, min(a.steps, 2))
             dt2, _, _, crf2, ppp2 = wl.timed_run(NOISE_HARD, n2, 1)

@@ -53,7 +53,9 @@ __global__ __launch_bounds__(NW * 64) void text_self_attn_kernel(const T* __rest
     for (int j = tid; j < L; j += NW * 64) madd[j] = (1.0f - (float)mask[(size_t)b * ld_mask + j]) * -10000.0f;
     __syncthreads();
     float* myp = pw + wave * TXT_MAX_L;
-    for (int i = wave; i < L; i += NW) {
+    // query rows are dealt over the waves of gridDim.z workgroups of the same (head, image) (each stages the head's K / V:
+    // a handful of workgroups cannot fill the chip when B * heads < CUs -- ADE20K at 768^2: 8 images x 12 heads, L = 155)
+    for (int i = wave + NW * blockIdx.z; i < L; i += NW * gridDim.z) {
         float* myq = qw + wave * 64;
         myq[lane] = to_f32(qkv[(row0 + i) * 3 * H + h * 64 + lane]);
         __builtin_amdgcn_wave_barrier();
@@ -100,7 +102,10 @@ __global__ __launch_bounds__(NW * 64) void text_self_attn_kernel(const T* __rest
 
 // Backward of the text self-attention: given dctx [B*L, H] (fp32), the stashed probs and q/k/v,
 // writes dqkv [B*L, 3H] (T).  Same staging; dS goes through a global scratch [B, heads, L, L].
-template <typename T>
+// PHASE 0: both phases in one workgroup per (head, image).  PHASE 1 / 2: phase A / phase B alone, as two launches whose rows
+// (query rows in A, key rows in B) are dealt over gridDim.z workgroups per (head, image) -- for batches too small to fill the
+// chip with one workgroup each (the launch boundary is the grid-wide hand-over of dS).
+template <typename T, int PHASE = 0>
 __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __restrict__ qkv, const float* __restrict__ dctx,
                                                                  const float* __restrict__ probs,
                                                                  float* __restrict__ ds_scratch, T* __restrict__ dqkv,
@@ -115,15 +120,16 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
     const size_t row0 = (size_t)b * L;
     const float* P = probs + ((size_t)b * nh + h) * L * L;
     float* dS = ds_scratch + ((size_t)b * nh + h) * L * L;
+    float* myp = pw + wave * TXT_MAX_L;
+    if (PHASE != 2) {
     for (int i = tid; i < L * 64; i += 256) {
         const int j = i >> 6, d = i & 63;
         as[j * 65 + d] = to_f32(qkv[(row0 + j) * 3 * H + H + h * 64 + d]);
         bs[j * 65 + d] = to_f32(qkv[(row0 + j) * 3 * H + 2 * H + h * 64 + d]);
     }
     __syncthreads();
-    float* myp = pw + wave * TXT_MAX_L;
     // phase A: per query row i: dP_ij = dctx_i . v_j ; dS = P (dP - sum_j dP P) ; dq_i = dS k / 8
-    for (int i = wave; i < L; i += 4) {
+    for (int i = wave + 4 * blockIdx.z; i < L; i += 4 * gridDim.z) {
         float* myg = qw + wave * 64;
         myg[lane] = dctx[(row0 + i) * H + h * 64 + lane];
         __builtin_amdgcn_wave_barrier();
@@ -158,7 +164,9 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
         dqkv[(row0 + i) * 3 * H + h * 64 + lane] = from_f32<T>(o * 0.125f);
         __builtin_amdgcn_wave_barrier();
     }
+    if (PHASE == 1) return;
     __syncthreads();
+    }
     // phase B: restage q and dctx, then per key row j: dk_j = dS^T q / 8 ; dv_j = P^T dctx
     for (int i = tid; i < L * 64; i += 256) {
         const int j = i >> 6, d = i & 63;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
     }
     __threadfence_block();
     __syncthreads();
-    for (int j = wave; j < L; j += 4) {
+    for (int j = wave + 4 * blockIdx.z; j < L; j += 4 * gridDim.z) {
         float dk = 0.f, dv = 0.f;
         for (int i = 0; i < L; i++) {
             const float ds = dS[(size_t)i * L + j];
@@ -652,6 +660,21 @@ int text_embed(const int64_t* ids, int ld_ids, const float* word, const float* p
 }
 
 static size_t self_attn_smem(int L, int nw = 4) { return (size_t)(2 * L * 65 + (nw + 1) * TXT_MAX_L + nw * 64) * sizeof(float); }
+// workgroups per (head, image) for the row-split launches: the nz in [1, 4] that minimises rounds(wg * nz) / nz (one LDS-bound
+// workgroup per CU; 96 pairs on 256 CUs: nz = 2 -> one round of half the rows; nz = 3 would be two rounds of a third)
+static int row_split(int pairs) {
+    const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    int best = 1;
+    double cost = 1e30;
+    for (int nz = 1; nz <= 4; nz++) {
+        const double c = (double)((pairs * nz + cus - 1) / cus) / nz;
+        if (c < cost - 1e-9) {
+            cost = c;
+            best = nz;
+        }
+    }
+    return best;
+}
 static size_t self_attn_long_smem(int L) { return (size_t)(L * 65 + 5 * TXT_LONG_L + 4 * 64) * sizeof(float); }
 
 // one-time per device: the kernels' opt-in to more than 64 KB of dynamic LDS (common.h: lds_opt_in)
@@ -680,6 +703,7 @@ int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, vo
         return ok();
     }
     const size_t smem = self_attn_smem(L);
+    if (L > 64) grid.z = row_split((int)grid.x * (int)grid.y);   // few (head, image) pairs: query rows over up to 4 workgroups each
     if (bf) {
         PNP_OPT_IN(text_self_attn_kernel<bf16>, self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_kernel<bf16>), grid, dim3(256), smem, s, (const bf16*)qkv, mask, ld_mask,
@@ -713,6 +737,17 @@ int text_self_attn_bwd(int bf, const void* qkv, const float* dctx, const float* 
         return ok();
     }
     const size_t smem = self_attn_smem(L);
+    if (!bf && L > 64 && row_split((int)grid.x * (int)grid.y) > 1) {
+        // too few (head, image) pairs for the chip: phase A and phase B as two launches, rows dealt over up to 4 workgroups each
+        grid.z = row_split((int)grid.x * (int)grid.y);
+        PNP_OPT_IN((text_self_attn_bwd_kernel<float, 1>), self_attn_smem(TXT_MAX_L));
+        hipLaunchKernelGGL((text_self_attn_bwd_kernel<float, 1>), grid, dim3(256), smem, s, (const float*)qkv, dctx, probs,
+                           ds_scratch, (float*)dqkv, L, H);
+        PNP_OPT_IN((text_self_attn_bwd_kernel<float, 2>), self_attn_smem(TXT_MAX_L));
+        hipLaunchKernelGGL((text_self_attn_bwd_kernel<float, 2>), grid, dim3(256), smem, s, (const float*)qkv, dctx, probs,
+                           ds_scratch, (float*)dqkv, L, H);
+        return ok();
+    }
     if (bf) {
         PNP_OPT_IN(text_self_attn_bwd_kernel<bf16>, self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_bwd_kernel<bf16>), grid, dim3(256), smem, s, (const bf16*)qkv, dctx, probs,
