@@ -24,6 +24,20 @@
 
 namespace pnp {
 
+// Streaming accesses of the mean-field kernels (data with no reuse inside a launch: contributor records, the value rows a splat
+// writes, the unary rows an update reads and the Q rows it writes) are marked non-temporal, so that they do not displace the
+// rows that ARE reused (a pixel's Q row is gathered by its 3 + 6 lattice points) from L2.  Round 5, same-box A/B
+// (tools/crf_nt_ab.sh, two alternations): mean-field per step 30.9 / 30.6 -> 30.3 / 30.6 ms on the headline batch (neutral),
+// 74.1 / 75.0 -> 72.5 / 72.9 ms at K = 59, 72.3 / 72.3 -> 67.3 / 71.1 ms at 3.6 lattice points per pixel, 252 / 257 -> 253 / 253 ms
+// at ADE20K size: small, never negative; the stores of the two-axis lattice blur on top of that: 30.6 / 30.8 -> 30.3 / 29.6 ms
+// (headline), 74.8 / 74.2 -> 73.1 / 73.1 (K = 59), 71.6 / 71.5 -> 69.7 / 66.6 (3.6 points per pixel).  Loads / stores are otherwise
+// identical: results unchanged.
+template <typename T> __device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T> __device__ __forceinline__ void st_stream(T* p, const T& v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ CrfEntry ld_entry(const CrfEntry* p) {
+    return __builtin_bit_cast(CrfEntry, ld_stream(reinterpret_cast<const chunk16*>(p)));
+}
+
 template <int D> struct KeyPack;
 template <> struct KeyPack<2> { static constexpr int BITS = 16; };
 template <> struct KeyPack<5> { static constexpr int BITS = 11; };
@@ -420,7 +434,7 @@ __global__ __launch_bounds__(256) void crf_splat_kernel(const CrfLattice L, cons
             e1n = L.seg_hi[lo + idl + stride];
         }
         CrfEntry first = none;
-        if (c0 < e1 - e0) first = L.ent[e0 + c0];
+        if (c0 < e1 - e0) first = ld_entry(L.ent + e0 + c0);
         f32x4 prev_acc = {0.f, 0.f, 0.f, 0.f};
         size_t prev_at = 0;
         bool have_prev = false;
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(256) void crf_splat_kernel(const CrfLattice L, cons
                     e0nn = L.seg_lo[lo + idl + 2 * stride];
                     e1nn = L.seg_hi[lo + idl + 2 * stride];
                 }
-                if (c0 < e1n - e0n) firstn = L.ent[e0n + c0];
+                if (c0 < e1n - e0n) firstn = ld_entry(L.ent + e0n + c0);
             };
             if (MULTI) prefetch();
             // MULTI: rows wider than LPP chunks take several passes over the point's records (cb loop; the prefetch then sits
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(256) void crf_splat_kernel(const CrfLattice L, cons
                 gather(first, 0, n, cofs, in);
                 if (!MULTI) {
                     prefetch();
-                    if (have_prev) V4[prev_at] = prev_acc;                // the previous point's row, stored under this point's gathers
+                    if (have_prev) st_stream(V4 + prev_at, prev_acc);     // the previous point's row, stored under this point's gathers
                     asm volatile("" ::: "memory");                        // (keeps every request above in front of the wait below)
                 }
                 accumulate(first, 0, n, in, acc);
@@ -478,14 +492,14 @@ __global__ __launch_bounds__(256) void crf_splat_kernel(const CrfLattice L, cons
                 }
                 for (int eb = e0 + LPP; eb < e1; eb += LPP) {
                     n = e1 - eb < LPP ? e1 - eb : LPP;
-                    const CrfEntry mine = c0 < n ? L.ent[eb + c0] : none;
+                    const CrfEntry mine = c0 < n ? ld_entry(L.ent + eb + c0) : none;
                     for (int j0 = 0; j0 < n; j0 += G) {
                         gather(mine, j0, n, cofs, in);
                         accumulate(mine, j0, n, in, acc);
                     }
                 }
                 if (MULTI) {
-                    if (cb + c0 < K4) V4[(size_t)idl * K4 + cb + c0] = acc;
+                    if (cb + c0 < K4) st_stream(V4 + (size_t)idl * K4 + cb + c0, acc);
                 } else {                                                  // stored one point later (a store waited for at the loop
                     prev_acc = acc;                                       // head would expose its acknowledge latency)
                     prev_at = (size_t)idl * K4 + c0;
@@ -495,7 +509,7 @@ __global__ __launch_bounds__(256) void crf_splat_kernel(const CrfLattice L, cons
             e0 = e0n; e1 = e1n; e0n = e0nn; e1n = e1nn;
             first = firstn;
         }
-        if (have_prev) V4[prev_at] = prev_acc;
+        if (have_prev) st_stream(V4 + prev_at, prev_acc);
     }
 }
 
@@ -599,7 +613,7 @@ __global__ __launch_bounds__(256) void crf_blur4x2_kernel(const CrfLattice L, co
             }
             CrfNbr8 tn = {-1, -1, -1, -1, -1, -1, -1, -1};
             if (it + stride < nitem) tn = T[pn];
-            if (prev_it >= 0) D4[prev_it] = prev;
+            if (prev_it >= 0) st_stream(D4 + prev_it, prev);   // (streamed: the next pass reads it back from beyond L2 either way)
             asm volatile("" ::: "memory");
             const f32x4 m_i = crf_blur1(r_i, r_ia, r_id);
             const f32x4 m_a = t.pa >= 0 ? crf_blur1(r_a, r_aa, r_ad) : zero;
@@ -610,7 +624,7 @@ __global__ __launch_bounds__(256) void crf_blur4x2_kernel(const CrfLattice L, co
             p = pn;
             c = cn;
         }
-        if (prev_it >= 0) D4[prev_it] = prev;
+        if (prev_it >= 0) st_stream(D4 + prev_it, prev);
     }
 }
 
@@ -697,7 +711,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
                     const int px = pixel_of(pl);
                     {
                         const uint32_t cofs = (uint32_t)c * 16u;
-                        const f32x4 u = *reinterpret_cast<const f32x4*>(Ub + (__umul24((uint32_t)px, rowb) + cofs));
+                        const f32x4 u = ld_stream(reinterpret_cast<const f32x4*>(Ub + (__umul24((uint32_t)px, rowb) + cofs)));
                         f32x4 t = {-u[0], -u[1], -u[2], -u[3]};
                         if (pairwise) {
                             f32x4 vg3[3], vb6[6];
@@ -784,7 +798,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
                 const int pl = item / K4, c = item - pl * K4;
                 if (inside(pl)) {
                     const float* r = tile + pl * ldt + 4 * c;
-                    Q4[(size_t)pixel_of(pl) * K4 + c] = f32x4{r[0], r[1], r[2], r[3]};
+                    st_stream(Q4 + (size_t)pixel_of(pl) * K4 + c, f32x4{r[0], r[1], r[2], r[3]});
                 }
             }
             __syncthreads();
