@@ -253,12 +253,12 @@ int pnp_get_buffer(pnp_engine* e, const char* name, void** d_ptr, size_t* bytes)
  * launches only). */
 int pnp_profile_enable(pnp_engine* e, int32_t on);
 int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms);
-/* Same for a pipeline stage: 0 = the dense GEMMs (as pnp_profile_read), 1 = the DenseCRF mean-field iterations
- * (PnP.py:1066-1072: splat / lattice blur / slice + update kernels of one batch, bracketed as a whole); `work` is
- * FLOPs for stage 0 and algorithmic bytes for stage 1, per mean-field iteration (2 x 9 + 2) x K x H x W x 4 (SURVEY.md 8d:
- * splat + slice over the 3 + 6 simplex vertices of a pixel, Q read + written) + 2 x (2 x M_gauss + 3 x M_bilateral) x K x 4 (the
- * lattice term: the value arrays of the M_* lattice points read and written once per two-axis blur pass), summed over the
- * iterations of the bracketed batches. */
+/* Same for a pipeline stage: 0 = the dense GEMMs (as pnp_profile_read); 1 = the DenseCRF mean-field iterations
+ * (PnP.py:1066-1072: splat / lattice blur / slice + update kernels of one batch, bracketed as a whole) with `work` =
+ * SURVEY.md 8d's algorithmic bytes and nothing else: per mean-field iteration (2 x 9 + 2) x K x H x W x 4 (splat + slice over
+ * the 3 + 6 simplex vertices of a pixel, Q read + written), summed over the iterations of the bracketed batches; 2 = the same
+ * brackets (same launches, same ms) with `work` = the lattice term that 8d leaves out: 2 x (2 x M_gauss + 3 x M_bilateral) x K x 4
+ * per iteration (the value arrays of the M_* lattice points read and written once per two-axis blur pass). */
 int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* launches, double* work, double* ms);
 /* Stand-alone operator entry points used by the parity tests (device pointers, see csrc/). */
 int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,

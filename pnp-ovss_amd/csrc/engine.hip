@@ -164,7 +164,8 @@ struct pnp_engine {
         std::vector<hipEvent_t> ev0, ev1;
         int used = 0;
         long long launches = 0;
-        double work = 0;
+        double work = 0;                       // SURVEY.md 8d bytes of the bracketed iterations
+        double lattice = 0;                    // lattice-blur term of the same brackets (reported separately)
     } crf_prof;
 };
 
@@ -1479,12 +1480,12 @@ static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t 
         (void)hipEventRecord(pf.ev1[pf.used], s);
         pf.used++;
         pf.launches++;
-        // per mean-field iteration splat + slice of (3 + 6) simplex vertices per pixel and channel, each
-        // a 4-byte read or write, plus Q read and written once: (2 * 9 + 2) * K * H * W * 4 bytes.  Round 4 adds the term that
-        // grows with the lattice, not with the pixels: the axis blurs read and write the value array of every lattice point
-        // (M_g + M_b points of K floats) once per PASS of two axes -- 2 passes for the Gaussian lattice (d + 1 = 3 axes), 3 for
-        // the bilateral one (6 axes); the published algorithm makes d + 1 -- so the fraction means the same at 0.9 and at 3.6
-        // lattice points per pixel
+        // `work` = SURVEY.md 8d, nothing else: per mean-field iteration splat + slice of (3 + 6) simplex vertices per pixel and
+        // channel, each a 4-byte read or write, plus Q read and written once: (2 * 9 + 2) * K * H * W * 4 bytes.  The term that grows
+        // with the lattice instead of the pixels is kept BESIDE it (`lattice`, stage 2 of pnp_profile_read_stage): the axis blurs
+        // read and write the value array of every lattice point (M_g + M_b points of K floats) once per PASS of two axes -- 2 passes
+        // for the Gaussian lattice (d + 1 = 3 axes), 3 for the bilateral one (6 axes).  Neither figure is what the HBM counters
+        // see (part of both is served by L2: the kernels are gather-bound)
         const auto& p = e->post;
         const int groups = desc == p.d_desc_pair ? 2 : 1;
         double kpix = 0, pix = 0;
@@ -1494,7 +1495,7 @@ static int crf_iterate(pnp_engine* e, const PostDesc* desc, int kp_max, int32_t 
         }
         const double kavg = pix > 0 ? kpix / pix : 0;
         pf.work += (double)iters * 20.0 * 4.0 * groups * kpix;
-        pf.work += (double)iters * 2.0 * 4.0 * groups * kavg * (2.0 * p.lat_points[0] + 3.0 * p.lat_points[1]);
+        pf.lattice += (double)iters * 2.0 * 4.0 * groups * kavg * (2.0 * p.lat_points[0] + 3.0 * p.lat_points[1]);
     }
     return r;
 }
@@ -1664,13 +1665,14 @@ extern "C" int pnp_profile_enable(pnp_engine* e, int32_t on) {
     e->crf_prof.used = 0;
     e->crf_prof.launches = 0;
     e->crf_prof.work = 0;
+    e->crf_prof.lattice = 0;
     return PNP_OK;
 }
 
 extern "C" int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* launches, double* work, double* ms) {
     if (!e || !launches || !work || !ms) return PNP_ERR_ARG;
     if (stage == 0) return pnp_profile_read(e, launches, work, ms);
-    if (stage != 1) return fail(e, PNP_ERR_ARG, "unknown profile stage %d", stage);
+    if (stage != 1 && stage != 2) return fail(e, PNP_ERR_ARG, "unknown profile stage %d", stage);
     auto& pf = e->crf_prof;
     double total = 0;
     for (int i = 0; i < pf.used; i++) {
@@ -1680,7 +1682,7 @@ extern "C" int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* lau
         total += t;
     }
     *launches = pf.launches;
-    *work = pf.work;
+    *work = stage == 1 ? pf.work : pf.lattice;
     *ms = total;
     return PNP_OK;
 }

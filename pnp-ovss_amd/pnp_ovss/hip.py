@@ -518,7 +518,8 @@ class Engine:
         return n.value, fl.value, ms.value
 
     def profile_read_stage(self, stage):
-        """stage 0: dense GEMMs (launches, FLOPs, ms); stage 1: DenseCRF mean-field (runs, algorithmic bytes, ms)."""
+        """stage 0: dense GEMMs (launches, FLOPs, ms); stage 1: DenseCRF mean-field (runs, SURVEY 8d bytes, ms);
+        stage 2: the same brackets with the lattice-blur bytes that 8d leaves out."""
         n, w, ms = C.c_int64(), C.c_double(), C.c_double()
         self._chk(self.lib.pnp_profile_read_stage(self.h, stage, C.byref(n), C.byref(w), C.byref(ms)), "pnp_profile_read_stage")
         return n.value, w.value, ms.value

@@ -185,3 +185,62 @@ def synth_tokens(cfg: ModelCfg, n_classes_per_image, seed: int = 1234, max_lengt
         ids[b, : len(toks)] = toks
     mask = (ids != cfg.pad_token_id).astype(np.int64)
     return ids, mask
+
+
+def inject_outliers(W, cfg, gain, seed=99, n=6, jitter=0.0, compensate=True):
+    """Outlier channels of the kind trained ViT-L checkpoints carry, as a FUNCTION-PRESERVING re-parametrisation: per ViT block
+    `n` channels of each LayerNorm (gain and bias) are scaled by `gain` and the matching input columns of the consuming Linear
+    (qkv / fc1) by 1 / gain; `n` value channels of qkv (rows + bias) by `gain` and the matching proj columns by 1 / gain; `n`
+    channels of the final LayerNorm by `gain` and the matching columns of all 12 cross-attention key / value projections by
+    1 / gain.  In exact arithmetic the model is unchanged; element-wise-relative arithmetic (fp32, split bf16) sees the same
+    relative errors; per-row-scaled integer slices lose log2(gain) bits on every other channel of the row.  (The GELU between
+    fc1 and fc2 does not commute with a scale, so fc2's input carries no injected outliers.)
+
+    With a power-of-two `gain` the scaled model is BIT-identical in any binary floating-point arithmetic (scaling by 2^k is
+    exact), which makes it a control, not a stress.  `jitter` > 0 draws a separate gain per channel, log-uniform in
+    [gain / (1 + jitter), gain * (1 + jitter)]: 1 / g is then rounded, every product and partial sum rounds differently from
+    the plain model's, and the two arithmetics under comparison part ways where they can.  `compensate=False` leaves the
+    consuming weights alone: the outlier channels then dominate every dot product they enter (a DIFFERENT model, with the
+    massive activations of a trained checkpoint), so the 2^-16 relative error of a split-bf16 product on the large terms is
+    an absolute error that the small, informative terms have to live with."""
+    g = np.random.default_rng(seed)
+    W = {k: v for k, v in W.items()}
+    D = cfg.vit_dim
+
+    def gains():
+        if jitter > 0:
+            return (np.float32(gain) * np.exp(g.uniform(-np.log1p(jitter), np.log1p(jitter), size=n))).astype(np.float32)
+        return np.full(n, gain, np.float32)
+
+    def scale(name, ch, f, axis):
+        w = W[name].copy()
+        if axis == 0:
+            w[ch] = w[ch] * (f if w.ndim == 1 else f[:, None])
+        else:
+            w[:, ch] = w[:, ch] * f[None, :]
+        W[name] = w
+
+    for i in range(cfg.vit_depth):
+        b = f"visual_encoder.blocks.{i}."
+        for nm, cons in (("norm1", "attn.qkv.weight"), ("norm2", "mlp.fc1.weight")):
+            ch = g.choice(D, n, replace=False)
+            f = gains()
+            for part in (".weight", ".bias"):
+                scale(b + nm + part, ch, f, 0)
+            if compensate:
+                scale(b + cons, ch, np.float32(1) / f, 1)
+        ch = g.choice(D, n, replace=False)
+        f = gains()
+        scale(b + "attn.qkv.weight", 2 * D + ch, f, 0)
+        scale(b + "attn.qkv.bias", 2 * D + ch, f, 0)
+        if compensate:
+            scale(b + "attn.proj.weight", ch, np.float32(1) / f, 1)
+    ch = g.choice(D, n, replace=False)
+    f = gains()
+    for part in (".weight", ".bias"):
+        scale("visual_encoder.norm" + part, ch, f, 0)
+    if compensate:
+        for i in range(cfg.txt_layers):
+            for kv in ("key", "value"):
+                scale(f"text_encoder.encoder.layer.{i}.crossattention.self.{kv}.weight", ch, np.float32(1) / f, 1)
+    return W

@@ -10,6 +10,7 @@ Fixtures (inputs are regenerated from seeds by pnp_ovss.synth; only outputs are 
   gradcam_large.npz   compute_gradcam_ensemble, BLIP-ITM-large 336^2, B=1, L=25: map [7][9] + logits
   droploop_small.npz  Inference_BLIP_filteredcaption (drop_iter 4 and 1), picks per iteration
   droploop_large.npz  the same at BLIP-ITM-large 336^2, B=2 ragged captions, drop_iter 4
+  droploop_large_outliers.npz  the same with outlier channels injected into the seeded weights (synth.inject_outliers)
   merge_tokens.npz    Mean_over_filtered_label_tokens on split / unsplit captions
   pipeline_voc.npz    save_img_union_attention end to end (blur / no post-process; CRF is not
   pipeline_psc.npz    importable here -> parity unpinned for CRF), hist .npy contents
@@ -176,12 +177,15 @@ def gen_droploop_small():
     print("droploop_small:", {k: v.shape for k, v in out.items()})
 
 
-def gen_droploop_large():
-    """Inference_BLIP_filteredcaption (PnP.py:564-722) at FULL model size: BLIP-ITM-large 336^2, B = 2 with ragged captions
-    (20 and 12 classes: the shorter row carries [SEP] and zero pad rows inside the [3:-1] salience slice), drop_iter 4:
-    gradcam_0, gradcam_agg and the patches zeroed in front of every iteration (= the picks so far)."""
+def _droploop_large(mutate=None):
+    """One reference run of Inference_BLIP_filteredcaption (PnP.py:564-722) at BLIP-ITM-large 336^2, B = 2 ragged captions, drop_iter 4;
+    `mutate(state_dict, cfg)` edits the seeded weights before they are loaded into the reference modules."""
     cfg = C.blip_itm_large(336)
-    m, itm, tok = _model(cfg, seed=0)
+    tok = SynthTokenizer(cfg.vocab)
+    sd = synth.synth_state_dict(cfg, 0)
+    if mutate is not None:
+        sd = mutate(sd, cfg)
+    m, itm = RL.build_reference_model(cfg, sd, tok)
     B, ncls = 2, [20, 12]
     _, imgs = synth.synth_images(B, 336, seed=2024)
     ids, mask = synth.synth_tokens(cfg, ncls, seed=2024)
@@ -215,10 +219,37 @@ def gen_droploop_large():
     norm_imgs = torch.zeros(B, 336, 336, 3)
     g0, agg = ns["Inference_BLIP_filteredcaption"](args, RL.DDPLike(m), tok500, torch.from_numpy(imgs.copy()), norm_imgs,
                                                    ["2007_000033", "2007_000042"], caps, [["c"] * n for n in ncls], "cpu")
+    return cfg, ncls, g0.numpy().astype(np.float32), agg.numpy().astype(np.float32), np.stack(rec["zeroed"])
+
+
+def gen_droploop_large():
+    """Inference_BLIP_filteredcaption (PnP.py:564-722) at FULL model size: BLIP-ITM-large 336^2, B = 2 with ragged captions
+    (20 and 12 classes: the shorter row carries [SEP] and zero pad rows inside the [3:-1] salience slice), drop_iter 4:
+    gradcam_0, gradcam_agg and the patches zeroed in front of every iteration (= the picks so far)."""
+    cfg, ncls, g0, agg, zeroed = _droploop_large()
     np.savez_compressed(os.path.join(HERE, "droploop_large.npz"), cfg=json.dumps(cfg.as_dict()), weight_seed=0, image_seed=2024,
-                        token_seed=2024, n_classes=np.array(ncls), g0=g0.numpy().astype(np.float32),
-                        agg=agg.numpy().astype(np.float32), zeroed=np.stack(rec["zeroed"]))
-    print("droploop_large:", g0.shape, agg.shape, np.stack(rec["zeroed"]).sum(axis=(1, 2)))
+                        token_seed=2024, n_classes=np.array(ncls), g0=g0, agg=agg, zeroed=zeroed)
+    print("droploop_large:", g0.shape, agg.shape, zeroed.sum(axis=(1, 2)))
+
+
+# heavy-tailed weights (the closest stand-in for a trained checkpoint this container offers): synth.inject_outliers variants of
+# the BLIP-large seed; the keyword sets are stored in the fixture so the tests rebuild the same weights
+OUTLIER_VARIANTS = {
+    "reparam16": dict(gain=16.0, jitter=0.5),                 # function-preserving, per-channel gains 10.7 .. 24 (not powers of two)
+    "reparam64": dict(gain=64.0, jitter=0.5, seed=7),        # own channel / gain draws (same seed: reparam16 x 4, bit-identical)
+    "massive8": dict(gain=8.0, jitter=0.5, compensate=False),  # consuming weights untouched: outlier channels dominate the dot products
+}
+
+
+def gen_droploop_large_outliers():
+    """gen_droploop_large's run with outlier channels injected into the seeded weights (OUTLIER_VARIANTS)."""
+    out = {}
+    for name, kw in OUTLIER_VARIANTS.items():
+        cfg, ncls, g0, agg, zeroed = _droploop_large(lambda sd, cfg_, kw=kw: synth.inject_outliers(sd, cfg_, **kw))
+        out[f"{name}_g0"], out[f"{name}_agg"], out[f"{name}_zeroed"] = g0, agg, zeroed
+        print("droploop_large_outliers", name, float(np.abs(g0).max()), float(np.abs(agg).max()), zeroed.sum(axis=(1, 2)), flush=True)
+    np.savez_compressed(os.path.join(HERE, "droploop_large_outliers.npz"), cfg=json.dumps(cfg.as_dict()), weight_seed=0,
+                        image_seed=2024, token_seed=2024, n_classes=np.array(ncls), variants=json.dumps(OUTLIER_VARIANTS), **out)
 
 
 def gen_merge_tokens():
@@ -723,7 +754,7 @@ GENS = dict(pipeline_voc_large=gen_pipeline_voc_large, gradcam_small=gen_gradcam
             pipeline_coco_object=gen_pipeline_coco_object, pipeline_coco_stuff=gen_pipeline_coco_stuff,
             gpt_parse_coco=gen_gpt_parse_coco, gpt_parse=gen_gpt_parse, tokenizer=gen_tokenizer,
             pos_embed=gen_pos_embed, checkpoint_small=gen_checkpoint_small,
-            droploop_large=gen_droploop_large, blur_cases=gen_blur_cases, hist_cases=gen_hist_cases, preprocess_cases=gen_preprocess_cases)
+            droploop_large=gen_droploop_large, droploop_large_outliers=gen_droploop_large_outliers, blur_cases=gen_blur_cases, hist_cases=gen_hist_cases, preprocess_cases=gen_preprocess_cases)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -733,6 +764,6 @@ if __name__ == "__main__":
     for name, fn in GENS.items():
         if a.only and name != a.only:
             continue
-        if a.skip_large and name in ("gradcam_large", "gradcam_large_768", "droploop_large", "pipeline_voc_large"):
+        if a.skip_large and name in ("gradcam_large", "gradcam_large_768", "droploop_large", "droploop_large_outliers", "pipeline_voc_large"):
             continue
         fn()

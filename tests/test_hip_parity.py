@@ -1262,6 +1262,51 @@ def test_drop_loop_large_vs_reference_golden(mode):
         assert _nerr(f"test_drop_loop_large_vs_reference_golden[{mode}] #8", gota[b, sl], g["agg"][b, sl]) < tol
 
 
+@pytest.mark.parametrize("variant", ["reparam16", "reparam64", "massive8"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_drop_loop_large_with_outlier_channels_vs_reference(mode, variant):
+    """Heavy-tailed weights through the HIP engine, against the reference (tests/golden/make_golden.py:gen_droploop_large_outliers:
+    the reference's own compute_gradcam_ensemble + Inference_BLIP_filteredcaption, B/blip_image_text_matching.py:386-457,
+    PnP.py:564-722, at BLIP-ITM-large 336^2, B = 2, drop_iter 4).  Seeded Gaussians have no outlier channels, trained ViT-L
+    checkpoints do; synth.inject_outliers plants them: `reparam16` / `reparam64` = 6 channels of every LayerNorm and 6 value
+    channels per block scaled by ~16 / ~64 (per-channel gains that are NOT powers of two, so every product rounds differently
+    from the plain model's) with the consuming weights scaled back -- the same function, 16-64x the dynamic range inside every
+    row the split-bf16 GEMMs see; `massive8` = the same channels x ~8 with the consuming weights left alone -- a different
+    model whose dot products are dominated by the outlier channels (the reference picks other patches than for the plain
+    seed: 208 cells of the `zeroed` record differ).  Both parity modes must pick the reference's patches in all 6
+    (iteration, image) pairs and hold north_star's 1e-4 on both maps."""
+    g = _golden("droploop_large_outliers.npz")
+    cfg = _cfg(g)
+    kw = json.loads(str(g["variants"]))[variant]
+    ncls = [int(x) for x in g["n_classes"]]
+    _, imgs = synth.synth_images(2, 336, seed=int(g["image_seed"]))
+    ids, mask = synth.synth_tokens(cfg, ncls, seed=int(g["token_seed"]))
+    L = int(mask.sum(1).max())
+    from pnp_ovss.hip import Engine
+    _ENG.clear()
+    e = Engine(cfg, max_batch=2, max_text_len=32, stash_layer=7, mode=mode)
+    e.load_state_dict(synth.inject_outliers(synth.synth_state_dict(cfg, int(g["weight_seed"])), cfg, **kw))
+    g0, agg, picks, _ = e.drop_loop(_dev(imgs), _dev(ids), _dev(mask), L, 9, 4)
+    torch.cuda.synchronize()
+    picks = picks.cpu().numpy()
+    got0, gota = g0.cpu().numpy(), agg.cpu().numpy()
+    e.close()
+    zeroed = g[f"{variant}_zeroed"]
+    assert zeroed.shape == (4, 2, 441) and zeroed[0].sum() == 0
+    for it in range(1, 4):
+        for b in range(2):
+            ref_set = set(np.nonzero(zeroed[it, b])[0].tolist())
+            assert len(ref_set) == 10 * it
+            assert ref_set == set(picks[b, : it * 10].tolist()), (mode, variant, it, b, sorted(ref_set ^ set(picks[b, : it * 10].tolist())))
+    r0, ra = g[f"{variant}_g0"], g[f"{variant}_agg"]
+    assert np.abs(got0 - r0).max() < 1e-4 and np.abs(gota - ra).max() < 1e-4
+    for b, n in enumerate(ncls):
+        sl = slice(3, 3 + n)
+        tag = f"test_drop_loop_large_with_outlier_channels_vs_reference[{mode}-{variant}]"
+        assert _nerr(tag + " g0", got0[b, sl], r0[b, sl]) < 2e-3
+        assert _nerr(tag + " agg", gota[b, sl], ra[b, sl]) < 2e-3
+
+
 def test_bf16x3_picks_equal_f32_at_blip_large_batch35():
     """Pick parity of the benchmarked mode at full model size AND at the bench's batch (B = 35: the wide GEMM's multi-tile
     launches, 732 / 976 tiles on 256 CUs, are part of what is compared): 35 images through BLIP-ITM-large 336^2, drop_iter 4,

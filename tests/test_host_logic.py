@@ -221,6 +221,30 @@ def test_bench_launches_its_own_ranks_dry_run_gloo():
     assert res["hist_total"] == 2 * 35 and res["images_per_rank"] == 70
 
 
+def test_bench_eight_rank_dress_rehearsal_gloo():
+    """The driver's 8-GPU scaling run rehearsed without an 8-GPU node (PnP.py:45-54 process group, :1218 weight broadcast,
+    :1439 one process per GPU): `bench.py --gpus 8 --dry-run --backend gloo` -- launcher, rendezvous at 127.0.0.1, the three
+    collectives of the path, the per-rank rate all-gather and the rank census on CPU tensors; the line carries the ranks the
+    communicator really joined and the memory / thread budget of 8 ranks x 3 engines, asserted against one GPU's HBM."""
+    out = _bench("--gpus", "8", "--backend", "gloo", "--dry-run", "--steps", "2", timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 8 and res["n_ranks"] == 8
+    assert res["rccl_ranks_seen"] == list(range(8)) and res["gathered_ranks"] == list(range(8))
+    assert len(res["per_rank_images_per_sec"]) == 8 and res["hist_total"] == 8 * 35
+    b = res["budget"]
+    assert b["ranks"] == 8 and b["engines_per_rank"] == 3 and b["host_threads_total"] == 32
+    assert b["device_GiB_per_rank"] < 0.9 * b["device_GiB_available"]
+
+
+def test_bench_budget_refuses_engines_that_do_not_fit():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.resource_budget(8, "coco80", 3)["device_GiB_per_rank"] > 150
+    with pytest.raises(AssertionError):
+        bench.resource_budget(8, "coco80", 5)
+
+
 def test_bench_launcher_propagates_a_failed_rank():
     out = _bench("--gpus", "2", "--backend", "gloo", "--dry-run", "--dry-run-fail-rank", "1", timeout=600)
     assert out.returncode != 0

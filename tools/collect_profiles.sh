@@ -4,7 +4,7 @@
 # under gpurun_out/ (tools/summarize_profiles.py turns them into the small committed files under profiles/).
 #   bash tools/collect_profiles.sh r04
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 R=$PWD
 OUT=$R/gpurun_out

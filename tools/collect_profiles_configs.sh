@@ -5,7 +5,7 @@
 # profiles/<tag>_{psc59,coco80,ade768}_kernel_stats_summary.txt and profiles/<tag>_{...}_crf_traffic.json.
 #   bash tools/collect_profiles_configs.sh r05 [configs...]
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 shift
 CFGS=${@:-psc59 coco80 ade768}
 export TMPDIR=/tmp
@@ -23,5 +23,8 @@ for cfg in $CFGS; do
       -- python3 $R/bench.py --config $cfg $B1 > $OUT/${TAG}_pmc_${cfg}_$c.log 2>&1
     echo "pmc $cfg $c rc=$?"
   done
+  rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --kernel-include-regex "crf_" -d $OUT/${TAG}_pmc_${cfg}_tcc -o pmc --output-format csv \
+    -- python3 $R/bench.py --config $cfg $B1 > $OUT/${TAG}_pmc_${cfg}_tcc.log 2>&1
+  echo "pmc $cfg tcc rc=$?"
 done
 ls $OUT | grep "^${TAG}_" | head -60

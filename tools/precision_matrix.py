@@ -57,6 +57,14 @@ def split(x):
     return hi, bf16r(x - hi)
 
 
+def split16(x):
+    """(hi, lo) fp16 pair of an fp32 tensor, as fp32 values: hi = fp16(x) (11 significant bits), lo = fp16(x - hi) (11 more where the
+    exponent range allows: fp16 subnormals below 6.1e-5 carry fewer bits, values below 6e-8 vanish -- torch's conversion keeps
+    subnormals, as v_mfma_f32_16x16x32_f16 does)."""
+    hi = x.to(torch.float16).to(F32)
+    return hi, (x - hi).to(torch.float16).to(F32)
+
+
 def mm_x3(a, bt):
     """a (.., M, K) @ bt (.., K, N), both split; small terms first like the kernels."""
     ah, al = split(a)
@@ -98,7 +106,7 @@ def int_slices(x, p):
 _TERMS = {"2x2_3": (2, 2, [(0, 0), (0, 1), (1, 0)]), "2x2_4": (2, 2, [(0, 0), (0, 1), (1, 0), (1, 1)]),
           "3x2_5": (3, 2, [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0)]),
           "3x3_6": (3, 3, [(0, 0), (0, 1), (1, 0), (1, 1), (2, 0), (0, 2)])}
-COST = {"f32": 16.0, "f64": None, "x3": 3.0, "x2w8": 2.0, "x2a8": 2.0, "i8_2x2_3": 1.5, "i8_2x2_4": 2.0, "i8_3x2_5": 2.5, "i8_3x3_6": 3.0}
+COST = {"f32": 16.0, "f64": None, "x3": 3.0, "x2w8": 2.0, "x2a8": 2.0, "h1": 1.0, "h2w11": 2.0, "h2a11": 2.0, "h3": 3.0, "i8_2x2_3": 1.5, "i8_2x2_4": 2.0, "i8_3x2_5": 2.5, "i8_3x3_6": 3.0}
 
 
 class Gemm:
@@ -132,7 +140,20 @@ class Gemm:
             if mode == "x2w8":
                 return al @ bh + ah @ bh
             return ah @ bl + ah @ bh
-        rot = mode.startswith("h")
+        if mode in ("h1", "h2w11", "h2a11", "h3"):
+            # fp16 operands (the fp16 MFMA issues at the bf16 rate): h1 = hi x hi, both operands at 11 bits (one MFMA per product);
+            # h2w11 = activations (hi, lo) x weights hi (weights at 11 bits); h2a11 = activations hi x weights (hi, lo); h3 = three
+            # terms like the split-bf16 form (22-bit operands; no saving -- calibration)
+            ah, al = split16(a)
+            bh, bl = self._w(w, "split16", lambda t: tuple(s.T.contiguous() for s in split16(t)))
+            if mode == "h1":
+                return ah @ bh
+            if mode == "h2w11":
+                return al @ bh + ah @ bh
+            if mode == "h2a11":
+                return ah @ bl + ah @ bh
+            return (ah @ bl + al @ bh) + ah @ bh
+        rot = mode.startswith("hi8")
         pa, pb, terms = _TERMS[mode[4:] if rot else mode[3:]]
         K = a.shape[1]
         ad = a.to(F64)
@@ -304,51 +325,7 @@ def drop_loop(model, imgs, ids, mask, drop_iter, layer, head, grid, patch):
     return preds[0].cpu().numpy(), agg.cpu().numpy(), newp
 
 
-def inject_outliers(W, cfg, gain, seed=99, n=6):
-    """Outlier channels of the kind trained ViT-L checkpoints carry, as a FUNCTION-PRESERVING re-parametrisation: per ViT block
-    `n` channels of each LayerNorm (gain and bias) are scaled by `gain` and the matching input columns of the consuming Linear
-    (qkv / fc1) by 1 / gain; `n` value channels of qkv (rows + bias) by `gain` and the matching proj columns by 1 / gain; `n`
-    channels of the final LayerNorm by `gain` and the matching columns of all 12 cross-attention key / value projections by
-    1 / gain.  In exact arithmetic the model is unchanged; element-wise-relative arithmetic (fp32, split bf16) sees the same
-    relative errors; per-row-scaled integer slices lose log2(gain) bits on every other channel of the row.  (The GELU between
-    fc1 and fc2 does not commute with a scale, so fc2's input carries no injected outliers.)"""
-    g = np.random.default_rng(seed)
-    W = {k: v for k, v in W.items()}
-    D = cfg.vit_dim
-    gain = np.float32(gain)
-    for i in range(cfg.vit_depth):
-        b = f"visual_encoder.blocks.{i}."
-        for nm, cons in (("norm1", "attn.qkv.weight"), ("norm2", "mlp.fc1.weight")):
-            ch = g.choice(D, n, replace=False)
-            for part in (".weight", ".bias"):
-                w = W[b + nm + part].copy()
-                w[ch] *= gain
-                W[b + nm + part] = w
-            w = W[b + cons].copy()
-            w[:, ch] /= gain
-            W[b + cons] = w
-        ch = g.choice(D, n, replace=False)
-        w = W[b + "attn.qkv.weight"].copy()
-        w[2 * D + ch] *= gain
-        W[b + "attn.qkv.weight"] = w
-        w = W[b + "attn.qkv.bias"].copy()
-        w[2 * D + ch] *= gain
-        W[b + "attn.qkv.bias"] = w
-        w = W[b + "attn.proj.weight"].copy()
-        w[:, ch] /= gain
-        W[b + "attn.proj.weight"] = w
-    ch = g.choice(D, n, replace=False)
-    for part in (".weight", ".bias"):
-        w = W["visual_encoder.norm" + part].copy()
-        w[ch] *= gain
-        W["visual_encoder.norm" + part] = w
-    for i in range(cfg.txt_layers):
-        for kv in ("key", "value"):
-            nm = f"text_encoder.encoder.layer.{i}.crossattention.self.{kv}.weight"
-            w = W[nm].copy()
-            w[:, ch] /= gain
-            W[nm] = w
-    return W
+inject_outliers = synth.inject_outliers          # the re-parametrisation lives with the other seeded generators
 
 
 def nerr(a, b):

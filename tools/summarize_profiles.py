@@ -55,7 +55,7 @@ def traffic(fetch_sub, write_sub, note_extra=""):
     fa, fn = pmc(fetch_sub)
     wa, wn = pmc(write_sub)
     tr = {"note": "HBM-side bytes per launch: FETCH_SIZE (KB, doubled: gfx950 reports half of wide coalesced reads) + WRITE_SIZE (KB)"
-                  + note_extra, "kernels": {}}
+                  + note_extra, "steps_profiled": 2, "kernels": {}}         # bench.py --steps 1 --warmup 1 under the profiler
     for k in fa:
         c = fn[k]["FETCH_SIZE"]
         w = wa.get(k, {}).get("WRITE_SIZE", 0.0) / max(wn.get(k, {}).get("WRITE_SIZE", 1), 1)
@@ -90,19 +90,27 @@ def main():
         tb = traffic("pmc_bf16_FETCH_SIZE", "pmc_bf16_WRITE_SIZE", " -- bf16 throughput mode")
         json.dump({"note": tb["note"], "kernels": {k: v for k, v in tb["kernels"].items() if "gemm_nt_wide" in k}},
                   open(os.path.join(P, f"{TAG}_gemm_traffic.json"), "w"), indent=1)
-    try:
-        ta, tn = pmc("pmc_tcc")
-        json.dump({k: {"l2_hit_rate": v["TCC_HIT_sum"] / max(v["TCC_HIT_sum"] + v["TCC_MISS_sum"], 1)} for k, v in ta.items()},
-                  open(os.path.join(P, f"{TAG}_crf_l2_hit.json"), "w"), indent=1)
-    except FileNotFoundError:
-        pass
+    def l2_hit(sub, out):
+        try:
+            ta, tn = pmc(sub)
+        except FileNotFoundError:
+            return
+        d = {"steps_profiled": 2}
+        for k, v in ta.items():
+            c = max(tn[k]["TCC_HIT_sum"], 1)
+            d[k] = {"l2_hit_rate": v["TCC_HIT_sum"] / max(v["TCC_HIT_sum"] + v["TCC_MISS_sum"], 1), "launches_profiled": c,
+                    "tcc_req_per_launch": (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]) / c}
+        json.dump(d, open(os.path.join(P, out), "w"), indent=1)
+
+    l2_hit("pmc_tcc", f"{TAG}_crf_l2_hit.json")
     for cfg in CFG_IMAGES:                              # BASELINE configs 3-5 (tools/collect_profiles_configs.sh)
         if os.path.exists(os.path.join(G, f"{TAG}_trace_{cfg}")):
             kernel_stats(f"trace_{cfg}", f"{TAG}_{cfg}_kernel_stats_summary.txt", cfg)
         if os.path.exists(os.path.join(G, f"{TAG}_pmc_{cfg}_FETCH_SIZE")):
             tc = traffic(f"pmc_{cfg}_FETCH_SIZE", f"pmc_{cfg}_WRITE_SIZE", f" -- config {cfg}, headline mode bf16x3, DenseCRF kernels")
-            json.dump({"note": tc["note"], "kernels": {k: v for k, v in tc["kernels"].items() if "crf_" in k}},
+            json.dump({"note": tc["note"], "steps_profiled": 2, "kernels": {k: v for k, v in tc["kernels"].items() if "crf_" in k}},
                       open(os.path.join(P, f"{TAG}_{cfg}_crf_traffic.json"), "w"), indent=1)
+        l2_hit(f"pmc_{cfg}_tcc", f"{TAG}_{cfg}_crf_l2_hit.json")
     b = os.path.join(G, f"{TAG}_bench.json")
     if os.path.exists(b):
         open(os.path.join(P, f"{TAG}_bench.json"), "w").write(open(b).read())
