@@ -260,6 +260,15 @@ int pnp_profile_read(pnp_engine* e, int64_t* launches, double* flops, double* ms
  * brackets (same launches, same ms) with `work` = the lattice term that 8d leaves out: 2 x (2 x M_gauss + 3 x M_bilateral) x K x 4
  * per iteration (the value arrays of the M_* lattice points read and written once per two-axis blur pass). */
 int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* launches, double* work, double* ms);
+/* Process-wide tuning switches (diagnostics and A/B measurements; the defaults are what is benchmarked).
+ *   "streamk": the stream-K tail of the persistent split-bf16 GEMM (the ViT Linears of B/vit.py:45-51, 93-117 at M = B * N rows):
+ *              0 = whole tiles only, 1 (default) = the last partial round of tiles is cut along K over all CUs when the cost
+ *              model says it pays, 2 = whenever a launch has a partial last round.  Results are deterministic in every
+ *              mode (fixed-order fix-up, no atomics) and differ between modes only by fp32 summation order. */
+int pnp_set_tuning(const char* key, int32_t value);
+/* Launches that used the engine's (e = NULL: the op-level entry points') stream-K workspace, and the give-up word of its
+ * bounded spins (0 = no owner ever gave up waiting for a partial tile; anything else is a bug report).  Synchronises. */
+int pnp_streamk_status(pnp_engine* e, int64_t* launches, uint32_t* gave_up);
 /* Stand-alone operator entry points used by the parity tests (device pointers, see csrc/). */
 int pnp_op_gemm(int32_t bf16, const void* d_A, int32_t lda, const void* d_B, int32_t ldb, int32_t M, int32_t N, int32_t K,
                 const float* d_bias, const float* d_resid, int32_t ldr, float* d_out_f32, int32_t ldo, int32_t gelu,

@@ -32,8 +32,13 @@ namespace pnp {
 // at ADE20K size: small, never negative; the stores of the two-axis lattice blur on top of that: 30.6 / 30.8 -> 30.3 / 29.6 ms
 // (headline), 74.8 / 74.2 -> 73.1 / 73.1 (K = 59), 71.6 / 71.5 -> 69.7 / 66.6 (3.6 points per pixel).  Loads / stores are otherwise
 // identical: results unchanged.
+#ifdef PNP_CRF_NO_NT            // A/B opt-out (tools/crf_nt_ab.sh builds its `base` variant with it): plain accesses
+template <typename T> __device__ __forceinline__ T ld_stream(const T* p) { return *p; }
+template <typename T> __device__ __forceinline__ void st_stream(T* p, const T& v) { *p = v; }
+#else
 template <typename T> __device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
 template <typename T> __device__ __forceinline__ void st_stream(T* p, const T& v) { __builtin_nontemporal_store(v, p); }
+#endif
 __device__ __forceinline__ CrfEntry ld_entry(const CrfEntry* p) {
     return __builtin_bit_cast(CrfEntry, ld_stream(reinterpret_cast<const chunk16*>(p)));
 }

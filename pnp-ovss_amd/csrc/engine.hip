@@ -157,6 +157,7 @@ struct pnp_engine {
     } post;
 
     GemmProfile* gemm_prof = nullptr;          // live timing ring of this engine's dense GEMM launches (allocated on first enable)
+    StreamKWs sk_ws;                           // partial tiles + flags of the in-launch reductions (split-bf16 mode: gemm_x3.hip)
     // live timing of one pipeline stage (bench.py's hbm roofline record for the DenseCRF mean-field): event pairs
     // on the launch stream around the stage, algorithmic bytes summed beside them
     struct StageProfile {
@@ -317,6 +318,7 @@ GemmArgs G_(const void* A, int lda, const void* B, int ldb, int M, int N, int K)
 // every GEMM of an engine goes through here: the launch is timed into the engine's own ring when profiling is on
 int egemm(pnp_engine* e, int bf, GemmArgs g, hipStream_t s) {
     g.prof = e->gemm_prof;
+    g.sk = e->sk_ws.part ? &e->sk_ws : nullptr;
     return gemm_nt(bf, g, s);
 }
 
@@ -370,6 +372,7 @@ extern "C" void pnp_destroy(pnp_engine* e) {
     }
     for (hipEvent_t ev : e->crf_prof.ev0) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->crf_prof.ev1) (void)hipEventDestroy(ev);
+    streamk_ws_destroy(&e->sk_ws);
     delete e;
 }
 
@@ -432,6 +435,11 @@ static int create_impl(const pnp_config* cfg, pnp_engine* donor, pnp_engine** ou
     e->vit.resize(c.vit_depth);
     e->txt.resize(TL);
     e->ta.resize(TL);
+    if (e->x3) {                               // one 256 KB partial-tile slot + one flag per CU (64 MB): not shared between engines
+        const int n_cu = device_cu_count();
+        if (!n_cu || streamk_ws_create(&e->sk_ws, n_cu) != PNP_OK) return fail(e, PNP_ERR_HIP, "stream-K workspace allocation failed");
+        e->alloc_bytes += (size_t)n_cu * 256 * 256 * 4;
+    }
     // activations
     KCHK(e, dalloc_t(e, &e->patches, B * e->PP * 768));
     KCHK(e, dalloc(e, &e->x, M * D));
@@ -1740,7 +1748,29 @@ extern "C" int pnp_op_gemm_x3(const void* d_A_hi, const void* d_A_lo, int32_t ld
     g.bias = d_bias; g.bias_on_rows = bias_on_rows; g.resid = d_resid; g.ldr = ldr; g.out_f32 = d_out_f32; g.ldo = ldo;
     g.out_t = d_out_hi; g.out_lo = d_out_lo; g.ldo_t = ldo_t; g.col_div = col_div; g.col_pad = col_pad;
     g.mode = gelu ? GEMM_EPI_GELU : GEMM_EPI_LINEAR;
+    g.sk = streamk_mode() ? streamk_ws_default() : nullptr;     // op level: the per-device workspace (calls on one stream at a time)
     return gemm_nt(1, g, (hipStream_t)stream);
+}
+
+extern "C" int pnp_set_tuning(const char* key, int32_t value) {
+    if (!key) return PNP_ERR_ARG;
+    if (!strcmp(key, "streamk")) {
+        if (value < 0 || value > 2) return PNP_ERR_ARG;
+        set_streamk_mode(value);
+        return PNP_OK;
+    }
+    return PNP_ERR_ARG;
+}
+
+extern "C" int pnp_streamk_status(pnp_engine* e, int64_t* launches, uint32_t* gave_up) {
+    if (!launches || !gave_up) return PNP_ERR_ARG;
+    StreamKWs* ws = e ? &e->sk_ws : streamk_ws_default();
+    *launches = ws ? ws->launches : 0;
+    *gave_up = 0;
+    if (!ws || !ws->part) return PNP_OK;
+    if (e) HIPCHK(e, hipSetDevice(e->c.device));
+    if (hipDeviceSynchronize() != hipSuccess) return PNP_ERR_HIP;
+    return streamk_ws_timeouts(ws, gave_up);
 }
 
 extern "C" int pnp_op_gemm_x3a(const float* d_A, int32_t lda, const void* d_B_hi, const void* d_B_lo, int32_t ldb, int32_t M,

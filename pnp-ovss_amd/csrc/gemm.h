@@ -8,6 +8,22 @@ enum { GEMM_EPI_LINEAR = 0, GEMM_EPI_GELU = 1, GEMM_EPI_GELU_GRAD = 2 };
 
 struct GemmProfile;
 
+// Workspace of the in-launch reductions (gemm_x3.hip stream-K tail; the text-side split-K): one per engine -- engines run
+// concurrently on their own streams -- sized for `wgs` workgroups.  part: wgs x 256 KB of fp32 partial tiles; flag: wgs ready
+// words + one give-up word (zeroed at allocation; every consumer resets the word it consumed, so launches need no memset).
+struct StreamKWs {
+    float* part = nullptr;
+    unsigned* flag = nullptr;
+    int wgs = 0;
+    long long launches = 0;        // launches that used the workspace (diagnostics)
+};
+int streamk_ws_create(StreamKWs* ws, int wgs);
+void streamk_ws_destroy(StreamKWs* ws);
+int streamk_ws_timeouts(StreamKWs* ws, unsigned* out);     // synchronises the device; *out = give-up word (0 = none)
+StreamKWs* streamk_ws_default();                          // per-device workspace of the op-level entry points (one stream at a time)
+void set_streamk_mode(int mode);
+int streamk_mode();
+
 struct GemmArgs {
     const void* A = nullptr;   // [M, lda] T
     const void* B = nullptr;   // [N, ldb] T
@@ -34,6 +50,11 @@ struct GemmArgs {
     int row_div = 0;               // >0: patch rows -> token rows b*(row_div+1)+1+p, resid = pos_embed
     int col_div = 0, col_pad = 0;  // >0: output column n -> (n / col_div) * col_pad + n % col_div
     struct GemmProfile* prof = nullptr;     // live timing ring of the calling engine (bench.py roofline), null = none
+    StreamKWs* sk = nullptr;                // workspace of the calling engine for the stream-K tail (null = data-parallel tiles only)
+    float* sk_part = nullptr;               // set by the launcher from `sk` when the tail is split: partial tiles, flags, give-up word,
+    unsigned* sk_flag = nullptr;            // tiles of the whole rounds, slab pairs per workgroup in the tail
+    unsigned* sk_tmo = nullptr;
+    int sk_full = 0, sk_upw = 0;
     unsigned long long* stamps = nullptr;   // diagnostics (DEV builds, PNP_GEMM_STAMPS): per-workgroup clock stamps, 8 per block
     int ablate = 0;                // DEV builds only (PNP_GEMM_ABLATE): 1 = no steady-state DMA, 2 = no MFMA
 };

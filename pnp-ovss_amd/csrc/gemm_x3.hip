@@ -27,8 +27,25 @@
 // per-lane SOURCE address of the DMA pieces and again on the fragment reads.
 // Accumulator layout (operands swapped at the MFMA, D = Btile * Atile^T): lane (r = l & 15, q = l >> 4) of tile (jm, in)
 // owns row m = 16 jm + r and the 4 consecutive columns n = 16 in + 4 q .. + 3.
+//
+// Stream-K tail (round 6, the SK instantiations): tiles come in rounds of one per CU, and the last round is rarely full
+// (732 / 976 / 244 tiles on 256 CUs at the bench batch; 292 / 876 / 1168 at 8 images of 768^2, where a round of 36 tiles costs
+// a whole tile time).  With SK the tiles of the whole rounds are walked as before and the TAIL tiles are cut along K into
+// 64-deep units (slab pairs) that are dealt over ALL workgroups in unit order, `sk_upw` units each: a workgroup's run covers
+// the end of one tile and / or the start of the next.  A part that does not reach its tile's end leaves its 256 x 256 fp32
+// partial sums in the workgroup's own 256 KB slot of a workspace (accumulator layout, 16-byte write-through stores, one
+// flag word per workgroup); the workgroup that holds the END of a tile adds the partial sums of the workgroups before it
+// in a fixed order (nearest first) and runs the tile's epilogue -- no atomics, results independent of timing.  A workgroup
+// runs its producing part BEFORE its owning part and a producer never waits, so an owner only ever waits for workgroups
+// with lower block ids, which were dispatched before it (observed dispatch order; HIP does not promise it, so every spin
+// is bounded and a give-up is recorded in a word the host can read: pnp_streamk_timeouts).  The hand-off is the guide's
+// write-through form (cdna_hip_programming.md Guideline 16, R1): every payload store `sc1`, every storing wave drains
+// vmcnt, one lane stores the flag `sc1`; the consumer polls that word with `sc1` loads, joins a workgroup barrier, and every
+// load of the payload is an `sc1` buffer load (no L1 copy can be stale, no agent-scope fence is needed).  The owner resets
+// the flag it consumed, so the state is clean for the next launch (and under graph replay).
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -62,7 +79,15 @@ __device__ __forceinline__ void x3_half(f32x4& c0, f32x4& c1, const frag16& ah, 
 
 // EPI: WIDE_RESID_F32 (+bias +residual -> fp32) | WIDE_BIAS_F32 (+bias -> fp32) | WIDE_TOKCOLS_F32 (per-row bias, token columns
 // remapped to per-image padded columns -> fp32) | WIDE_GELU_SPLIT (+bias, erf-GELU -> (hi, lo) bf16 pair) | WIDE_SPLIT (+bias -> pair)
-template <int EPI>
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+#ifdef PNP_SK_PLAIN            // experiment: plain payload + agent-scope release / acquire fences instead of write-through stores
+#define PNP_SK_AUX 0
+#else
+#define PNP_SK_AUX 16          // sc1
+#endif
+
+template <int EPI, bool SK>
 __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
     constexpr int BM = 256, BN = 256, SLOT = 65536, ARR = 16384;
     constexpr int JM = 8, IN = 4;                   // 16 x 16 tiles per wave: 128 (m) x 64 (n)
@@ -151,6 +176,12 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
                                        // kernel contains: tests/test_cabi_cpu.py::test_m0_is_written_only_by_the_asm_lds_dma checks the
                                        // disassembly of the shipped code object for exactly that
     };
+    auto stamp_sk = [&](int slot) {                 // stream-K phases of this workgroup, in the stamp rows behind the grid's own
+        if (g.stamps && tid == 0) {
+            g.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + slot] = __builtin_readcyclecounter();
+            g.stamps[((size_t)gridDim.x + blockIdx.x) * 8 + 4 + slot] = wall_clock64();
+        }
+    };
     auto stamp = [&](int slot) {
         if (g.stamps && tid == 0) {
             g.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_readcyclecounter();
@@ -171,14 +202,58 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
     asm volatile("" : "+v"(fa_off[1]), "+v"(fb_off[1]));
     float* const stg = reinterpret_cast<float*>(smem + SLOT) + wave * (32 * SROW);
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
+    // ---- work list of this workgroup (everything wave-uniform).  Whole rounds: tiles blockIdx.x + i * gridDim.x below `full`
+    // (= every tile when the stream-K tail is off).  Tail (SK): units [bid * upw, (bid + 1) * upw) of the tail tiles' slab
+    // pairs; P = the part of that run that does not reach its tile's end (partial sums -> workspace), O = the part that does
+    // (adds the parts of the workgroups before it, then the epilogue).  Order: whole tiles, P, O
+    // Nothing of the list is kept in registers across the tile loop (this kernel has no scalar register to spare: what does not fit
+    // is parked in vector registers, and those belong to the accumulators): the item is recomputed from the kernel arguments
+    const int bid = blockIdx.x;
+    enum { kWhole = 0, kProduce = 1, kOwn = 2 };
+    auto get_work = [&](int wi, int& t, int& k0, int& k1, int& kind) {
+        const int grid = gridDim.x;
+        const int full = SK ? g.sk_full : ntiles;
+        t = bid + wi * grid;
+        if (t < full) {
+            k0 = 0;
+            k1 = nk;
+            kind = kWhole;
+            return true;
+        }
+        if constexpr (SK) {
+            const int j = wi - g.sk_full / grid;             // every workgroup walks the same number of whole tiles
+            const int nk2 = nk >> 1;
+            const int T = (ntiles - full) * nk2;
+            const int u0 = bid * g.sk_upw;
+            const int u1 = u0 + g.sk_upw < T ? u0 + g.sk_upw : T;
+            if (u0 >= u1 || j > 1) return false;
+            const int ta = u0 / nk2, bnd = (ta + 1) * nk2;
+            const bool owns = u1 >= bnd, two = u1 > bnd;     // reaches the end of tile ta | goes on into tile ta + 1
+            if (j == 0 && (two || !owns)) {                  // the producing part first
+                t = full + ta + (two ? 1 : 0);
+                k0 = two ? 0 : 2 * (u0 - ta * nk2);
+                k1 = 2 * (u1 - (two ? bnd : ta * nk2));
+                kind = kProduce;
+                return true;
+            }
+            if (owns && (j == 0 || two)) {
+                t = full + ta;
+                k0 = 2 * (u0 - ta * nk2);
+                k1 = nk;
+                kind = k0 ? kOwn : kWhole;
+                return true;
+            }
+        }
+        return false;
+    };
+    int wi = 0, tile, k0, k1, kind;
+    if (!get_work(0, tile, k0, k1, kind)) return;
     int m0, n0;
     bool drain32 = false;                           // the previous tile's epilogue left >= kDrain stores behind this tile's slab 0
     stamp(0);
     set_tile(tile, m0, n0, lane);
 #pragma unroll
-    for (int i = 0; i < NDMA; i++) issue_one(0, i, 1u);
+    for (int i = 0; i < NDMA; i++) issue_one(k0, i, 1u);
 
     for (;;) {
         f32x4 acc[JM][IN];
@@ -214,7 +289,7 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
         else PNP_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();               // slab 0 complete; staging area (slot 1) no longer read
 #pragma unroll
-        for (int i = 0; i < NDMA; i++) issue_one(1, i, 1u);
+        for (int i = 0; i < NDMA; i++) issue_one(k0 + 1, i, 1u);      // k0 is even and every part is at least one slab pair
         rd_a(0, 0, 0);
         rd_a(1, 0, 1);
         rd_a(2, 0, 2);
@@ -234,8 +309,8 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
         // the "next" slab run on whatever the other slot holds: harmless, and the same code for every slab.
         auto slab = [&](int kt, auto par) {
             constexpr int S = decltype(par)::value;
-            const uint32_t head = __builtin_amdgcn_readfirstlane((kt >= 1 && kt + 1 < nk) ? 1 : 0);
-            const uint32_t tail = __builtin_amdgcn_readfirstlane((kt + 2 < nk) ? 1 : 0);
+            const uint32_t head = __builtin_amdgcn_readfirstlane((kt >= k0 + 1 && kt + 1 < k1) ? 1 : 0);
+            const uint32_t tail = __builtin_amdgcn_readfirstlane((kt + 2 < k1) ? 1 : 0);
 #pragma unroll
             for (int j = 0; j < JM; j++) {
                 x3_half(acc[j][0], acc[j][1], ah[j & 3], al[j & 3], bh[S][0], bh[S][1], bl[S][0], bl[S][1]);
@@ -271,15 +346,112 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
         };
         constexpr std::integral_constant<int, 0> s0{};
         constexpr std::integral_constant<int, 1> s1{};
-        for (int kt = 0; kt < nk; kt += 2) {        // nk is even
+        for (int kt = k0; kt < k1; kt += 2) {       // k0, k1 even
             slab(kt, s0);
             slab(kt + 1, s1);
         }
         // the compiler does not see the MFMAs inside the asm blocks: cover the matrix-pipe -> VALU read hazard of the last ones
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-        if (tile == (int)blockIdx.x) stamp(2);
+        if (wi == 0) stamp(2);
 
         __syncthreads();                            // every wave is done reading the last slab: both slots are free
+        int ntile, nk0, nk1, nkind;
+        const bool have_next = get_work(wi + 1, ntile, nk0, nk1, nkind);
+        // slab 0 of the next part flies during this one's epilogue (see request_next below for where it is issued)
+        auto request_next = [&]() {
+            if (have_next) {
+                set_tile(ntile, m0, n0, lane);
+#pragma unroll
+                for (int i = 0; i < NDMA; i++) issue_one(nk0, i, 1u);
+            }
+        };
+        if constexpr (SK) {
+            if (kind == kProduce) {
+                // partial sums of this part -> own workspace slot, accumulator layout: store (jm, in) of lane t at
+                // float4 index (jm * 4 + in) * 512 + t, i.e. every store instruction writes 1 KB per wave, contiguous
+                stamp_sk(0);
+                request_next();
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.sk_part + (size_t)bid * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#if !defined(PNP_SK_ABLATE) || PNP_SK_ABLATE < 1 || PNP_SK_ABLATE == 3     // timing-only builds (tools/gemm_x3_streamk.py --lib): 1 = no
+                {                                     // partial-tile traffic, 2 = also no flag wait, 3 = stores only, 4 = loads only
+                    // ONE lane-offset register walks the 32 pieces (8 KB apart): offsets folded into 32 constants would cost 32 scalar
+                    // registers this kernel does not have (the allocator then parks accumulators in scratch memory)
+                    int voff = tid * 16;
+#pragma unroll
+                    for (int j = 0; j < JM; j++)
+#pragma unroll
+                        for (int i = 0; i < IN; i++) {
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[j][i]), rs, voff, 0, PNP_SK_AUX);   // aux 16 = sc1
+                            voff += 8192;
+                            asm volatile("" : "+v"(voff));
+                        }
+                }
+#endif
+#ifdef PNP_SK_PLAIN
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+#endif
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the flag is raised
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store((gu32*)(g.sk_flag + bid), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                stamp_sk(1);
+            }
+            if (kind == kOwn) {
+                const int np = ((k0 >> 1) + g.sk_upw - 1) / g.sk_upw;       // workgroups bid - 1 .. bid - np hold the parts before k0
+                stamp_sk(2);
+                for (int pj = 1; pj <= np; pj++) {
+                    const int src = bid - pj;
+                    if (wave == 0) {
+                        gu32* const fl = (gu32*)(g.sk_flag + src);
+                        uint32_t spins = 0;
+#if defined(PNP_SK_ABLATE) && PNP_SK_ABLATE >= 2
+                        while (false) {
+#else
+                        while (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
+#endif
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 22)) {                      // ~1 s: give up loudly instead of hanging the device
+                                if (lane == 0) __hip_atomic_store((gu32*)g.sk_tmo, 1u + (uint32_t)bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                        }
+                        if (lane == 0) __hip_atomic_store(fl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next launch
+                    }
+                    __syncthreads();
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.sk_part + (size_t)src * (BM * BN), 0, BM * BN * 4, 0x00020000);
+#ifdef PNP_SK_PLAIN
+                    if (tid == 0) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __syncthreads();
+#endif
+#if !defined(PNP_SK_ABLATE) || PNP_SK_ABLATE < 1 || PNP_SK_ABLATE == 4
+                    int voff = tid * 16;
+#pragma unroll
+                    for (int grp = 0; grp < 4; grp++) {
+                        u32x4 t[8];
+#pragma unroll
+                        for (int x = 0; x < 8; x++) {
+                            t[x] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, PNP_SK_AUX);
+                            voff += 8192;
+                            asm volatile("" : "+v"(voff));
+                        }
+#pragma unroll
+                        for (int x = 0; x < 8; x++) acc[(grp * 8 + x) / IN][(grp * 8 + x) % IN] += __builtin_bit_cast(f32x4, t[x]);
+                    }
+#endif
+                }
+                stamp_sk(3);
+            }
+        }
+        bool next_drain = false;
+        if (!SK || kind != kProduce) {              // (one exit of the tile body for both kinds of part: a `continue` out of the middle
+                                                    // left the allocator two loop edges to reconcile, through scratch memory)
         // everything the epilogue derives from the lane id is RE-derived here from an opaque copy of the thread id: computed
         // once in front of the k loop (where the compiler would otherwise put it) these ~15 values are live across a loop that
         // has no register to spare, and are spilled around it -- with scratch reloads whose vmcnt waits also wait for the DMA
@@ -321,18 +493,10 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
                 if (g.bias && m < g.M) brow[j] = g.bias[m];
             }
         }
-        const int next = tile + gridDim.x;
         // slab 0 of the next tile flies during this tile's epilogue.  It is requested right BEHIND the first use of the operands
         // loaded above (bias, first residual rows): vmcnt is one in-order counter and the compiler does not see the pieces (asm),
         // so its wait for those loads would count the pieces as landed-before -- issued in front of that wait they would be
         // waited for with it (~3 us per tile measured); loads issued later wait for the pieces anyway, by then long landed
-        auto request_next = [&]() {
-            if (next < ntiles) {
-                set_tile(next, m0, n0, lane);
-#pragma unroll
-                for (int i = 0; i < NDMA; i++) issue_one(0, i, 1u);
-            }
-        };
 
         if constexpr (EPI == WIDE_TOKCOLS_F32) {
             // 32-row quarters staged as fp32 with the row bias added in the accumulator layout; on the way out a lane owns a
@@ -468,11 +632,17 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
                 if (qd == 0) request_next();
             }
         }
-        if (tile == (int)blockIdx.x) stamp(1);     // diagnostics: first tile's epilogue done (stores issued)
-        if (next >= ntiles) break;
-        tile = next;
         // every lane of a full tile executes all of the epilogue's stores (8 per quarter and wave, 64 for the split pair)
-        drain32 = (EPI != WIDE_TOKCOLS_F32) && (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+        next_drain = (EPI != WIDE_TOKCOLS_F32) && (em0 + BM <= g.M) && (en0 + BN <= g.Nvalid);
+        }
+        if (wi == 0) stamp(1);                     // diagnostics: first tile's epilogue done (stores issued)
+        if (!have_next) break;
+        wi++;
+        tile = ntile;
+        k0 = nk0;
+        k1 = nk1;
+        kind = nkind;
+        drain32 = next_drain;
     }
     if (g.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -480,21 +650,106 @@ __global__ __launch_bounds__(512) void gemm_nt_x3_kernel(const GemmArgs g) {
     }
 }
 
+// Stream-K tail policy, in units of one slab pair of one workgroup (4.2 us at the clock these launches hold).  Measured with the
+// in-kernel stamps (tools/gemm_x3_streamk_stamps.py, profiles/r06_streamk_stamps.txt) and per launch shape
+// (tools/gemm_x3_streamk.py, profiles/r06_streamk.txt):
+//   whole tiles : the tail round costs a tile, nk2 pairs + ~2 of epilogue -- x 0.82 when the tail holds under a quarter of the CUs
+//                 (the few workgroups of such a round run beside idle CUs, at a higher rate: 58 against 75 us at K = 1024);
+//   stream-K    : 1.05 x upw pairs in two parts, each with its own pipeline fill (~2 pairs each); the partial tile stored and
+//                 the flag raised: 3-7 us when up to ~64 tiles are split, 19 us when most workgroups store 256 KB at the same time
+//                 beside the others' operand streams (220 producers of the 732-tile launch); ~4 us per partial tile an owner
+//                 adds (np of them, one after the other); the epilogue.
+// So the hand-off costs 8-12 pairs = 35-50 us: it pays for a SMALL tail of DEEP tiles (8 x 2305 rows, fc2: 292 tiles of K = 4096,
+// 501 -> 382 us; 12 x 442 rows: 84 tiles, 202 -> 146 us), is worth +-5 % for small tails at K = 1024 (left off), and loses 10-35 us
+// on the bench batch's launches (732 / 976 / 244 tiles), where a whole tile is 75 us.  mode: 0 = never, 1 = when this model says it pays, 2 = whenever
+// there is a tail (tests, A/B runs); set process-wide by pnp_set_tuning("streamk", mode).
+static std::atomic<int> g_streamk_mode{1};
+void set_streamk_mode(int m) { g_streamk_mode.store(m, std::memory_order_relaxed); }
+int streamk_mode() { return g_streamk_mode.load(std::memory_order_relaxed); }
+static bool streamk_pays(int tail, int cap, int nk2, int upw, int np) {
+    // a tail round that leaves CUs idle runs its tiles FASTER than a full round (clock and memory system to itself): 0.73-0.82 of
+    // the full-round tile time up to ~60 % of the CUs, 0.96 at 80 %, 1.05 at 95 % (K = 4096 launches of 84 ... 244 tiles)
+    const double x = (double)tail / cap;
+    const double whole = (nk2 + 2.0) * (x <= 0.6 ? 0.75 : 0.75 + (x - 0.6) * 0.857);
+    const double sk = 1.05 * upw + 4.0 + (tail <= 64 ? 1.0 : 4.5) + 0.75 * np + 1.5;
+    return sk * 1.05 + 0.5 < whole;                 // at least 5 % of the tail round, or it is not worth a second code path
+}
+
 template <int EPI>
-static int launch_x3(const GemmArgs& g, hipStream_t s) {
+static int launch_x3(GemmArgs g, hipStream_t s) {
     const int nbm = (g.M + 255) / 256, nbn = g.N / 256;
     const int n_cu = device_cu_count();
     if (!n_cu) return PNP_ERR_HIP;
-    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
-    if (lds_opt_in(opted, reinterpret_cast<const void*>(gemm_nt_x3_kernel<EPI>), kWideSmem) != PNP_OK) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted{0}, opted_sk{0};            // per device ordinal (common.h: lds_opt_in)
     const int ntiles = nbm * nbn;
     int cap = n_cu;
 #ifdef PNP_DEV
     if (getenv("PNP_GEMM_GRID")) cap = atoi(getenv("PNP_GEMM_GRID"));
 #endif
+    const int mode = streamk_mode();
+    StreamKWs* const ws = g.sk;
+    if (mode && ws && ws->part && ws->wgs >= cap) {
+        const int rounds = ntiles / cap, tail = ntiles - rounds * cap, nk2 = g.K / 64;
+        if (tail > 0) {
+            const int upw = (int)(((long)tail * nk2 + cap - 1) / cap);
+            const int np = (nk2 - 1 + upw - 1) / upw;                    // parts in front of the last one of a tile, at most
+            if (mode == 2 || streamk_pays(tail, cap, nk2, upw, np)) {
+                if (lds_opt_in(opted_sk, reinterpret_cast<const void*>(gemm_nt_x3_kernel<EPI, true>), kWideSmem) != PNP_OK) return PNP_ERR_HIP;
+                g.sk_part = ws->part;
+                g.sk_flag = ws->flag;
+                g.sk_tmo = ws->flag + ws->wgs;
+                g.sk_full = rounds * cap;
+                g.sk_upw = upw;
+                ws->launches++;
+                hipLaunchKernelGGL((gemm_nt_x3_kernel<EPI, true>), dim3(cap), dim3(512), kWideSmem, s, g);
+                return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+            }
+        }
+    }
+    if (lds_opt_in(opted, reinterpret_cast<const void*>(gemm_nt_x3_kernel<EPI, false>), kWideSmem) != PNP_OK) return PNP_ERR_HIP;
     const int grid = ntiles > cap ? cap : ntiles;        // one workgroup per CU (LDS-limited) walks the tiles
-    hipLaunchKernelGGL((gemm_nt_x3_kernel<EPI>), dim3(grid), dim3(512), kWideSmem, s, g);
+    hipLaunchKernelGGL((gemm_nt_x3_kernel<EPI, false>), dim3(grid), dim3(512), kWideSmem, s, g);
     return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+int streamk_ws_create(StreamKWs* ws, int wgs) {
+    if (!ws || wgs <= 0) return PNP_ERR_ARG;
+    const size_t fbytes = ((size_t)(wgs + 1) * 4 + 15) / 16 * 16;
+    if (hipMalloc(&ws->part, (size_t)wgs * 256 * 256 * 4) != hipSuccess) return PNP_ERR_HIP;
+    if (hipMalloc(&ws->flag, fbytes) != hipSuccess || hipMemset(ws->flag, 0, fbytes) != hipSuccess) {
+        (void)hipFree(ws->part);
+        ws->part = nullptr;
+        return PNP_ERR_HIP;
+    }
+    ws->wgs = wgs;
+    return PNP_OK;
+}
+
+void streamk_ws_destroy(StreamKWs* ws) {
+    if (!ws) return;
+    if (ws->part) (void)hipFree(ws->part);
+    if (ws->flag) (void)hipFree(ws->flag);
+    *ws = StreamKWs();
+}
+
+int streamk_ws_timeouts(StreamKWs* ws, unsigned* out) {
+    if (!ws || !out) return PNP_ERR_ARG;
+    *out = 0;
+    if (!ws->flag) return PNP_OK;
+    return hipMemcpy(out, ws->flag + ws->wgs, 4, hipMemcpyDeviceToHost) == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+}
+
+StreamKWs* streamk_ws_default() {
+    static StreamKWs ws[kMaxDevices];
+    static std::mutex mu;
+    const int d = current_device();
+    if (d < 0) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!ws[d].part) {
+        const int n = device_cu_count();
+        if (!n || streamk_ws_create(&ws[d], n) != PNP_OK) return nullptr;
+    }
+    return &ws[d];
 }
 
 int launch_x3_wide(int epi, const GemmArgs& g, hipStream_t s) {

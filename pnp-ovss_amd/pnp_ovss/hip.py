@@ -96,6 +96,8 @@ def load_library():
         "pnp_op_xattn": (i32, [i32, i32, vp, i32, vp, i32, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp]),
         "pnp_op_sort_pairs": (i32, [vp, vp, vp, vp, i64, i32, i32, vp, i32, vp]),
         "pnp_op_scan_i32": (i32, [vp, vp, i64, i32, vp]),
+        "pnp_set_tuning": (i32, [C.c_char_p, i32]),
+        "pnp_streamk_status": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_uint32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = ABI drift, fail loudly
@@ -112,7 +114,8 @@ EXPORTED = ["pnp_create", "pnp_create_shared", "pnp_destroy", "pnp_last_error", 
             "pnp_remap_hist", "pnp_postprocess", "pnp_postprocess_pair", "pnp_get_buffer", "pnp_profile_enable", "pnp_profile_read", "pnp_op_gemm", "pnp_op_gemm_ex", "pnp_op_layernorm", "pnp_op_cast", "pnp_op_xattn", "pnp_dbg_gemm_stamps", "pnp_op_gemm_tokcols", "pnp_op_vit_attention", "pnp_preprocess_images",
             "pnp_cross_kv", "pnp_profile_read_stage", "pnp_op_split", "pnp_op_gemm_x3", "pnp_op_gemm_x3a",
             "pnp_xattn_grad_layer", "pnp_compute_gradcam_layer", "pnp_drop_loop_layer", "pnp_allocated_bytes",
-            "pnp_op_vit_attention_x3", "pnp_jpeg_decode", "pnp_op_sort_pairs", "pnp_op_scan_i32"]
+            "pnp_op_vit_attention_x3", "pnp_jpeg_decode", "pnp_op_sort_pairs", "pnp_op_scan_i32", "pnp_set_tuning",
+            "pnp_streamk_status"]
 
 
 class _DevView:
@@ -524,6 +527,12 @@ class Engine:
         self._chk(self.lib.pnp_profile_read_stage(self.h, stage, C.byref(n), C.byref(w), C.byref(ms)), "pnp_profile_read_stage")
         return n.value, w.value, ms.value
 
+    def streamk_status(self):
+        """(launches of this engine that split their last tile round along K, give-up word of the bounded spins: 0 = none)."""
+        n, t = C.c_int64(), C.c_uint32()
+        self._chk(self.lib.pnp_streamk_status(self.h, C.byref(n), C.byref(t)), "pnp_streamk_status")
+        return n.value, t.value
+
     # ------------------------------------------------------------------ introspection
     def buffer(self, name, dtype=torch.float32):
         p, n = C.c_void_p(), C.c_size_t()
@@ -556,3 +565,19 @@ class Engine:
             out.append(flat[o:o + kp * h * w].view(h * w, kp)[:, :k])
             o += kp * h * w
         return out
+
+
+def set_tuning(key, value):
+    """Process-wide tuning switch (include/pnp_hip.h: pnp_set_tuning), e.g. set_tuning("streamk", 0 | 1 | 2)."""
+    r = load_library().pnp_set_tuning(key.encode(), int(value))
+    if r != 0:
+        raise ValueError(f"pnp_set_tuning({key!r}, {value}) -> {r}")
+
+
+def streamk_status_ops():
+    """pnp_streamk_status of the op-level entry points' workspace."""
+    n, t = C.c_int64(), C.c_uint32()
+    r = load_library().pnp_streamk_status(None, C.byref(n), C.byref(t))
+    if r != 0:
+        raise RuntimeError(f"pnp_streamk_status -> {r}")
+    return n.value, t.value
