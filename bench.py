@@ -55,13 +55,14 @@ CONFIGS = {
                    pipelines=3,
                    what="COCO-Object-shaped (BASELINE config 4, one GPU's share): 336x336, batch 35, 80-class prompt (L=85, K=81), "
                         "COCO driver rules: N-drop branch only (drop_iter >= 3), Scale_0_1, category-id labels, 91-row histogram"),
-    # batch 7, not 8: 7 x 2305 = 16 135 token rows are 63.03 row tiles of the persistent 256 x 256 GEMM -- 64 x 4 / 12 / 16 tiles =
-    # exactly 1 / 3 / 4 rounds on 256 CUs -- where 8 x 2305 = 18 440 rows (72.03 -> 73 row tiles) pay 2 / 4 / 5 rounds for a last
-    # row tile of 8 rows (round 5, tools/ade_sweep.sh: GEMM 0.134 -> 0.163 of peak, 14.7 -> 15.1 images/s)
-    "ade768": dict(img=768, classes=150, data_type="ade20k", hist=151, batch=7, skip_1drop=False, scale01=(True, False), crf_chunk=1,
+    # batch 8 again (round 6).  Round 5 ran 7: 8 x 2305 = 18 440 token rows are 72.03 -> 73 row tiles of the persistent 256 x 256 GEMM,
+    # i.e. 292 / 876 / 1168 tiles = 2 / 4 / 5 rounds on 256 CUs where 7 images pay exactly 1 / 3 / 4.  The stream-K tail of the
+    # split-bf16 GEMM (csrc/gemm_x3.hip) now cuts fc2's 36-tile second round over all CUs (501 -> 382 us per launch); per image the
+    # two batch sizes are level (14.65 / 14.73 images/s, tools/gemm_x3_streamk.py, profiles/r06_ade_batch.txt)
+    "ade768": dict(img=768, classes=150, data_type="ade20k", hist=151, batch=8, skip_1drop=False, scale01=(True, False), crf_chunk=1,
                    pipelines=2,
                    what="ADE20K-shaped (BASELINE config 5, one GPU's share): 768x768 (2305 image tokens, pos-embed grid 48x48), "
-                        "7 images per step, 150-class prompt (L=155, K=150), blur radius 154, DenseCRF one image per launch group"),
+                        "8 images per step, 150-class prompt (L=155, K=150), blur radius 154, DenseCRF one image per launch group"),
 }
 
 

@@ -95,7 +95,10 @@ struct pnp_engine {
     // ---- activations
     int ldq = 0;               // row stride (elements) of the fused q|k|v buffer
     float* x0 = nullptr;       // [M, D] token embeddings of drop iteration 0 (patch embed + pos, cls row): later iterations reuse them
-    // what the reusable state was computed from (embed == 1 call): an embed == 2 call that does not match recomputes instead
+    // what the reusable state was computed from (embed == 1 call): an embed == 2 call that does not match recomputes instead.
+    // CONTRACT: the record catches stale POINTERS and SHAPES, not stale CONTENTS -- a caller that refills the same image / id
+    // buffers in place between an embed == 1 and an embed == 2 call gets the old embeddings (the one caller, pnp_drop_loop_layer,
+    // always starts a batch with embed == 1; pnp_vit_forward / pnp_text_forward_xattn invalidate the record)
     struct { const float* images = nullptr; const int64_t* ids = nullptr; const int64_t* mask = nullptr; int B = 0, L = 0, ld = 0;
              bool vit = false, text = false; } reuse;
     void *patches = nullptr, *xn = nullptr, *qk = nullptr, *vt = nullptr, *ctx = nullptr, *h1 = nullptr, *embT = nullptr;

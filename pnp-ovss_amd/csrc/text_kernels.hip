@@ -3,6 +3,8 @@
 // Reference: med.py:88-123 (embeddings), :191-311 (attention; probs stash + grad hook at :280-283),
 //            :321-325 / :393-411 (post-LN dense blocks), :776-852 (additive masks),
 //            blip_image_text_matching.py:238-249 (enc token, itm head), :399-404 (loss + backward).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -660,14 +662,21 @@ int text_embed(const int64_t* ids, int ld_ids, const float* word, const float* p
 }
 
 static size_t self_attn_smem(int L, int nw = 4) { return (size_t)(2 * L * 65 + (nw + 1) * TXT_MAX_L + nw * 64) * sizeof(float); }
-// workgroups per (head, image) for the row-split launches: the nz in [1, 4] that minimises rounds(wg * nz) / nz (one LDS-bound
-// workgroup per CU; 96 pairs on 256 CUs: nz = 2 -> one round of half the rows; nz = 3 would be two rounds of a third)
-static int row_split(int pairs) {
+// workgroups per (head, image) for the row-split launches: the nz in [1, 4] that minimises rounds(pairs * nz) / nz, a round being
+// what is RESIDENT at once: CUs x workgroups per CU at this caption length's LDS use (about 100 KB at L = 155: one per CU, 96 pairs
+// -> nz = 2, one round of half the rows; 49 KB at L = 85: three per CU, 420 pairs -> nz = 3, two rounds of a third)
+static int row_split(int pairs, size_t smem) {
     const int cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    int per_cu = (int)(160 * 1024 / (smem ? smem : 1));
+    per_cu = per_cu < 1 ? 1 : per_cu > 8 ? 8 : per_cu;
+    const int slots = cus * per_cu;
+#ifdef PNP_DEV
+    if (getenv("PNP_TXT_NZ")) return atoi(getenv("PNP_TXT_NZ"));
+#endif
     int best = 1;
     double cost = 1e30;
     for (int nz = 1; nz <= 4; nz++) {
-        const double c = (double)((pairs * nz + cus - 1) / cus) / nz;
+        const double c = (double)((pairs * nz + slots - 1) / slots) / nz;
         if (c < cost - 1e-9) {
             cost = c;
             best = nz;
@@ -703,7 +712,7 @@ int text_self_attn(int bf, const void* qkv, const int64_t* mask, int ld_mask, vo
         return ok();
     }
     const size_t smem = self_attn_smem(L);
-    if (L > 64) grid.z = row_split((int)grid.x * (int)grid.y);   // few (head, image) pairs: query rows over up to 4 workgroups each
+    if (L > 64) grid.z = row_split((int)grid.x * (int)grid.y, smem);   // few (head, image) pairs: query rows over up to 4 workgroups each
     if (bf) {
         PNP_OPT_IN(text_self_attn_kernel<bf16>, self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_kernel<bf16>), grid, dim3(256), smem, s, (const bf16*)qkv, mask, ld_mask,
@@ -737,9 +746,9 @@ int text_self_attn_bwd(int bf, const void* qkv, const float* dctx, const float* 
         return ok();
     }
     const size_t smem = self_attn_smem(L);
-    if (!bf && L > 64 && row_split((int)grid.x * (int)grid.y) > 1) {
+    if (!bf && L > 64 && row_split((int)grid.x * (int)grid.y, smem) > 1) {
         // too few (head, image) pairs for the chip: phase A and phase B as two launches, rows dealt over up to 4 workgroups each
-        grid.z = row_split((int)grid.x * (int)grid.y);
+        grid.z = row_split((int)grid.x * (int)grid.y, smem);
         PNP_OPT_IN((text_self_attn_bwd_kernel<float, 1>), self_attn_smem(TXT_MAX_L));
         hipLaunchKernelGGL((text_self_attn_bwd_kernel<float, 1>), grid, dim3(256), smem, s, (const float*)qkv, dctx, probs,
                            ds_scratch, (float*)dqkv, L, H);

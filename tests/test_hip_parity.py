@@ -1370,7 +1370,10 @@ def test_drop_loop_large_with_outlier_channels_vs_reference(mode, variant):
     for b, n in enumerate(ncls):
         sl = slice(3, 3 + n)
         tag = f"test_drop_loop_large_with_outlier_channels_vs_reference[{mode}-{variant}]"
-        tol = 6e-3 if variant == "massive8" else 2e-3
+        # measured on MI355X: reparam16 / reparam64 <= 2.4e-4 (f32), 5.8e-4 (bf16x3) -- the plain seed's 2.2e-4 / 3.0e-4 class; massive8
+        # 8.8e-4 (f32), 2.0e-3 .. 2.3e-3 (bf16x3): dot products dominated by the outlier channels cost the split-bf16 products ~2.5x
+        # the exact-fp32 error on the normalised maps, the picks hold in both.  Bounds ~2.5x the measurement
+        tol = 5e-3 if variant == "massive8" else 1.5e-3
         assert _nerr(tag + " g0", got0[b, sl], r0[b, sl]) < tol
         assert _nerr(tag + " agg", gota[b, sl], ra[b, sl]) < tol
 

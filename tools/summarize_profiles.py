@@ -18,7 +18,7 @@ def short(name):
     return name.replace("(anonymous namespace)::", "").replace("pnp::", "").split("(")[0][:80]
 
 
-CFG_IMAGES = {"psc59": 35, "coco80": 35, "ade768": 7}
+CFG_IMAGES = {"psc59": 35, "coco80": 35, "ade768": 8}
 
 
 def kernel_stats(sub, out, cfg=None):
