@@ -37,8 +37,12 @@
 // flag word per workgroup); the workgroup that holds the END of a tile adds the partial sums of the workgroups before it
 // in a fixed order (nearest first) and runs the tile's epilogue -- no atomics, results independent of timing.  A workgroup
 // runs its producing part BEFORE its owning part and a producer never waits, so an owner only ever waits for workgroups
-// with lower block ids, which were dispatched before it (observed dispatch order; HIP does not promise it, so every spin
-// is bounded and a give-up is recorded in a word the host can read: pnp_streamk_timeouts).  The hand-off is the guide's
+// of its own launch with lower block ids.  Those were handed to the dispatcher before it, but each XCD deals its share of the
+// grid at its own pace, so "lower id" means "started, or waiting for a CU that something else holds": progress then depends on
+// that something not being another launch of this kind waiting the other way round.  The launcher therefore keeps ONE
+// stream-K launch in flight per device (an event chain across streams, launch_x3), beside which only kernels that never
+// spin can hold CUs; and every spin is bounded all the same, a give-up recorded in a word the host reads
+// (pnp_streamk_status) instead of a hung device.  The hand-off is the guide's
 // write-through form (cdna_hip_programming.md Guideline 16, R1): every payload store `sc1`, every storing wave drains
 // vmcnt, one lane stores the flag `sc1`; the consumer polls that word with `sc1` loads, joins a workgroup barrier, and every
 // load of the payload is an `sc1` buffer load (no L1 copy can be stale, no agent-scope fence is needed).  The owner resets
@@ -701,8 +705,23 @@ static int launch_x3(GemmArgs g, hipStream_t s) {
                 g.sk_full = rounds * cap;
                 g.sk_upw = upw;
                 ws->launches++;
+                // ONE stream-K launch in flight per device: an owner spins on workgroups of its own launch with lower ids, which
+                // the dispatcher started before it -- true within a launch, but two such launches from two streams, each resident on
+                // part of the chip, could hold the CUs the other's missing producers need.  Every launch waits for the event behind the
+                // previous one (whatever stream it was on) and leaves its own; kernels that never spin overlap with it as before
+                static std::mutex mu;
+                static hipEvent_t last[kMaxDevices];
+                const int d = current_device();
+                if (d < 0) return PNP_ERR_HIP;
+                std::lock_guard<std::mutex> lk(mu);
+                if (!last[d]) {
+                    if (hipEventCreateWithFlags(&last[d], hipEventDisableTiming) != hipSuccess) return PNP_ERR_HIP;
+                } else if (hipStreamWaitEvent(s, last[d], 0) != hipSuccess) {
+                    return PNP_ERR_HIP;
+                }
                 hipLaunchKernelGGL((gemm_nt_x3_kernel<EPI, true>), dim3(cap), dim3(512), kWideSmem, s, g);
-                return hipGetLastError() == hipSuccess ? PNP_OK : PNP_ERR_HIP;
+                const bool ok = hipGetLastError() == hipSuccess && hipEventRecord(last[d], s) == hipSuccess;
+                return ok ? PNP_OK : PNP_ERR_HIP;
             }
         }
     }

@@ -353,6 +353,43 @@ def test_gemm_stream_k_is_deterministic_and_timing_independent(streamk_forced):
     assert hip.streamk_status_ops()[1] == 0
 
 
+def test_gemm_stream_k_launches_from_two_streams_do_not_meet(streamk_forced):
+    """Two streams issue stream-K launches back to back (the engines of a multi-pipeline run do): the launcher chains them through
+    an event per device -- one launch with spinning owners in flight at a time, so no launch can sit on the CUs another's
+    producers need -- and they may even share the op-level workspace.  Outputs equal the one-stream results bit for bit."""
+    hip = streamk_forced
+    lib = hip.load_library()
+    g = torch.Generator().manual_seed(11)
+    cases = []
+    for (M, N, K) in ((18440, 1024, 1024), (5304, 1024, 4096)):
+        A = torch.randn(M, K, generator=g).cuda()
+        B = (torch.randn(N, K, generator=g) * 0.05).cuda()
+        cases.append((M, N, K, _split(A), _split(B), torch.randn(N, generator=g).cuda()))
+    p = lambda t: t.data_ptr()
+
+    def run(c, out, stream):
+        M, N, K, (Ah, Al), (Bh, Bl), bias = c
+        assert lib.pnp_op_gemm_x3(p(Ah), p(Al), K, p(Bh), p(Bl), K, M, N, K, p(bias), 0, None, 0, p(out), N, None, None, 0, 0, 0, 0,
+                                  stream.cuda_stream) == 0
+    main = torch.cuda.current_stream()
+    refs = []
+    for c in cases:
+        o = torch.empty(c[0], c[1], device="cuda")
+        run(c, o, main)
+        torch.cuda.synchronize()
+        refs.append(o)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(4):
+        outs = [torch.empty_like(r) for r in refs]
+        run(cases[0], outs[0], s1)
+        run(cases[1], outs[1], s2)
+        run(cases[0], outs[0], s2)
+        run(cases[1], outs[1], s1)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], refs[0]) and torch.equal(outs[1], refs[1]), rep
+    assert hip.streamk_status_ops()[1] == 0
+
+
 @pytest.mark.parametrize("shape", [(875, 768, 768), (875, 2304, 768), (875, 768, 3072), (875, 3072, 768), (130, 3072, 768), (1, 768, 32), (64, 64, 2304)])
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_gemm_split_bf16_text_side(shape, mode):
