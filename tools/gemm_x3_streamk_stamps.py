@@ -43,9 +43,10 @@ for mode in (0, 2):
     st = np.zeros((nb, 8), dtype=np.uint64)
     assert lib.pnp_dbg_gemm_stamps(st.ctypes.data, nb) == 0
     wall = st[:, 4:].astype(np.int64)
-    t0 = wall[:256, 0].min()
+    nwg = int((wall[:256, 0] > 0).sum()) if mode == 0 else 256        # whole-tile launches of fewer tiles than CUs use fewer workgroups
+    t0 = wall[:nwg, 0].min()
     us = (wall - t0) / 100.0
-    g, k = us[:256], us[256:]
+    g, k = us[:nwg], us[256:]
     print(f"mode {mode}: M={M} N={N} K={K}: span {g[:, 3].max():.1f} us; start spread {g[:, 0].max():.1f}; first tile main loop end (median) {np.median(g[:, 2]):.1f}, "
           f"first epilogue done {np.median(g[:, 1]):.1f}; workgroup done: min {g[:, 3].min():.1f} median {np.median(g[:, 3]):.1f} max {g[:, 3].max():.1f}")
     if mode == 2:
