@@ -665,10 +665,11 @@ def run_rank(a):
                                         "and written once per pass of two blur axes",
                                 "frac_with_it": (nbytes + lattice) / sec / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0},
                "bilateral_lattice_points_per_pixel": ppp,
-               "what_bounds_it": "the nine value-row gathers per pixel and the contributor-list walks are served by L2 (hit rates below), "
-                                 "so the kernels run at the L2 -> CU gather rate and at gather latency, not at the HBM rate: counter_frac "
-                                 "(bytes that actually crossed the fabric) sits at or below frac, and neither approaches the 0.79 "
-                                 "(6.3 of 8 TB/s) the guide calls achievable"}
+               "what_bounds_it": "neither memory bandwidth: counter_frac (bytes that actually crossed the fabric: part of the algorithmic "
+                                 "bytes is served by L2, hit rates below) sits at or below frac and far from the 0.79 (6.3 of 8 TB/s) the guide "
+                                 "calls achievable, and the L2 request rate (l2_gather) is about a quarter of the 34 TB/s the L2s deliver.  The "
+                                 "kernels are dependent-load chains (contributor list -> Q rows; neighbour record -> nine value rows) and run at "
+                                 "gather latency x the occupancy their registers allow (DESIGN.md section 3)"}
         cn = crf_counters(name, noise) if name else None
         if cn and ms > 0:
             per_step_s = sec / max(steps, 1)
