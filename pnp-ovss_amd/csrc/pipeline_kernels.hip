@@ -369,13 +369,15 @@ __device__ __forceinline__ int reflect_fast(int i, int n) {
 //   axis 0 (vertical):   xs[(32 NT + 2r)][64],     thread = (column c, row group of 8) per sub-tile
 //   axis 1 (horizontal): xs[32][colsP], colsP = 64 NT + 2r rounded up to odd (conflict-free row stride),
 //                        thread = (row, column group of 8) per sub-tile
+template <int AXIS>
 __global__ __launch_bounds__(1024) void blur_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                         const PostDesc* __restrict__ desc, const double* __restrict__ wts,
-                                                        const int32_t* __restrict__ wt_off, int axis, int max_radius, int NT) {
+                                                        const int32_t* __restrict__ wt_off, int max_radius, int NT) {
+    constexpr int axis = AXIS;                                           // one kernel per pass: each keeps only its own staging code
     constexpr int TH = 32, TW = 64;
     extern __shared__ __attribute__((aligned(16))) double tile[];
     double* wl = tile;                                                   // [max_radius + 1] taps
-    float* xs = reinterpret_cast<float*>(tile + (max_radius + 2));       // staged samples
+    float* xs = reinterpret_cast<float*>(tile + ((max_radius + 3) & ~1));  // staged samples (16-byte aligned: the vertical pass stages 16-byte pieces)
     const int b = blockIdx.z, k = blockIdx.y;
     const PostDesc d = desc[b];
     if (k >= d.K) return;
@@ -395,12 +397,32 @@ __global__ __launch_bounds__(1024) void blur_axis_kernel(const float* __restrict
         const int y0 = ty * THe, x0 = tx * TWe;
         __syncthreads();
         double acc[8];
-        if (axis == 0) {
+        if constexpr (AXIS == 0) {
             const int rows = THe + 2 * radius;           // xs[rows][TW]
             const int c = tid & 63;
             const int x = x0 + c < W ? x0 + c : W - 1;
             // eight independent loads in flight per thread (a one-load-per-iteration loop made the whole kernel
-            // wait on global latency: the arithmetic of a tile is ~1 us, its staging was ~20 us)
+            // wait on global latency: the arithmetic of a tile is ~1 us, its staging was ~20 us).  Round 6: 16-byte pieces where
+            // the rows allow it (W a multiple of 4, a full-width tile, an aligned plane) -- with 4-byte loads a workgroup had 8 KB in
+            // flight and staged its 42 KB tile + halo in six latency-bound passes, half of the launch
+            if ((W & 3) == 0 && x0 + TW <= W && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                const int c4 = (tid & 15) * 4;
+                const int rp = nthr >> 4;                // rows staged per pass of the workgroup
+                for (int r0 = tid >> 4; r0 < rows; r0 += 8 * rp) {
+                    f32x4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int r = r0 + rp * u;
+                        v[u] = r < rows ? *reinterpret_cast<const f32x4*>(src + (size_t)reflect_fast(y0 - radius + r, H) * W + x0 + c4)
+                                        : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const int r = r0 + rp * u;
+                        if (r < rows) *reinterpret_cast<f32x4*>(xs + r * TW + c4) = v[u];
+                    }
+                }
+            } else {
             const int rp = nthr >> 6;                    // rows staged per pass of the workgroup
             for (int r0 = tid >> 6; r0 < rows; r0 += 8 * rp) {
                 float v[8];
@@ -414,6 +436,7 @@ __global__ __launch_bounds__(1024) void blur_axis_kernel(const float* __restrict
                     const int r = r0 + rp * u;
                     if (r < rows) xs[r * TW + c] = v[u];
                 }
+            }
             }
             __syncthreads();
             {
@@ -429,17 +452,19 @@ __global__ __launch_bounds__(1024) void blur_axis_kernel(const float* __restrict
         } else {
             // flat (row, column) index so all 256 threads load, eight independent loads in flight each
             const int total = TH * colsP;
-            for (int i0 = tid; i0 < total; i0 += 8 * nthr) {
-                float v[8];
+            constexpr int NF = 16;                       // loads in flight per thread (round 6: 16, was 8: 198-float rows at arbitrary
+                                                         // offsets with reflected ends stay 4-byte loads, so depth is what is left)
+            for (int i0 = tid; i0 < total; i0 += NF * nthr) {
+                float v[NF];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < NF; u++) {
                     const int i = i0 + u * nthr;
                     const int r = i / colsP, c = i - r * colsP;
                     const int y = y0 + r < H ? y0 + r : H - 1;
                     v[u] = i < total ? src[(size_t)y * W + reflect_fast(x0 - radius + c, W)] : 0.f;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < NF; u++) {
                     const int i = i0 + u * nthr;
                     if (i < total) xs[i] = v[u];
                 }
@@ -833,8 +858,8 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
     // nothing overlaps the staging any more and the tile grows to as many as fit ~120 KB (at most 4): 23.5 -> 18.2 ms per
     // launch at ADE20K size, where a 1-sub-tile launch at radius 67 is 6 % faster than a 4-sub-tile one
     auto lds_for = [&](int n, size_t& l0, size_t& l1) {
-        l0 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)(32 * n + 2 * max_radius) * 64 * sizeof(float);
-        l1 = (size_t)(max_radius + 2) * sizeof(double) + (size_t)32 * ((64 * n + 2 * max_radius) | 1) * sizeof(float);
+        l0 = (size_t)(max_radius + 4) * sizeof(double) + (size_t)(32 * n + 2 * max_radius) * 64 * sizeof(float);
+        l1 = (size_t)(max_radius + 4) * sizeof(double) + (size_t)32 * ((64 * n + 2 * max_radius) | 1) * sizeof(float);
     };
     size_t lds0, lds1;
     lds_for(1, lds0, lds1);
@@ -852,12 +877,13 @@ int blur_maps(const float* in, float* tmp, float* out, const PostDesc* desc, con
     size_t d0, d1;
     lds_for(nt1, d0, d1);
     lds1 = d1;
-    static std::atomic<uint32_t> opted{0};            // per device ordinal (common.h: lds_opt_in)
-    if (lds_opt_in(opted, reinterpret_cast<const void*>(blur_axis_kernel), 160 * 1024) != PNP_OK) return PNP_ERR_HIP;
+    static std::atomic<uint32_t> opted0{0}, opted1{0};  // per device ordinal (common.h: lds_opt_in)
+    if (lds_opt_in(opted0, reinterpret_cast<const void*>(blur_axis_kernel<0>), 160 * 1024) != PNP_OK) return PNP_ERR_HIP;
+    if (lds_opt_in(opted1, reinterpret_cast<const void*>(blur_axis_kernel<1>), 160 * 1024) != PNP_OK) return PNP_ERR_HIP;
     const int tiles0 = ((maxW + 63) / 64) * ((maxH + 32 * nt0 - 1) / (32 * nt0));
     const int tiles1 = ((maxW + 64 * nt1 - 1) / (64 * nt1)) * ((maxH + 31) / 32);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles0, Kmax, B), dim3(256 * nt0), lds0, s, in, tmp, desc, wts, wt_off, 0, max_radius, nt0);
-    hipLaunchKernelGGL(blur_axis_kernel, dim3(tiles1, Kmax, B), dim3(256 * nt1), lds1, s, tmp, out, desc, wts, wt_off, 1, max_radius, nt1);
+    hipLaunchKernelGGL(blur_axis_kernel<0>, dim3(tiles0, Kmax, B), dim3(256 * nt0), lds0, s, in, tmp, desc, wts, wt_off, max_radius, nt0);
+    hipLaunchKernelGGL(blur_axis_kernel<1>, dim3(tiles1, Kmax, B), dim3(256 * nt1), lds1, s, tmp, out, desc, wts, wt_off, max_radius, nt1);
     return ok();
 }
 
