@@ -641,8 +641,15 @@ __global__ __launch_bounds__(256) void crf_blur4x2_kernel(const CrfLattice L, co
 // neighbours in both directions (Gaussian cells are 3 px wide, lattice points are numbered along a Z-order curve), so a block
 // touches about half the distinct value rows of a strip of the same size and the slice gathers hit L1 / L2 accordingly.
 constexpr int CRF_TP = 256;
+// channels per group from which the update's softmax runs wave-parallel (see there).  Measured (tools/cfg_kstats.sh): K = 150 (32-pixel
+// tiles, 64 rows: the thread-per-row form keeps ONE wave busy) 1350 -> 1169 us per launch; K = 81 / 59 (64 / 128 rows) 1654 -> 2514 /
+// 1947 -> 3029 us -- a row's dependent chain (LDS read, six shuffles, exponential, store) is too long where rows are many and short
+constexpr int CRF_WAVE_SOFTMAX_K = 128;
 __host__ __device__ inline int crf_tile_w(int tp) { return tp >= 128 ? 16 : tp >= 32 ? 8 : 4; }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void crf_update_kernel(const CrfLattice Lg, const CrfLattice Lb, const PostDesc* __restrict__ imgs,
+// WIDE (rows of >= CRF_WAVE_SOFTMAX_K channels per group): the wave-parallel softmax below; such tiles are LDS-bound to three
+// workgroups per CU, so the kernel may use 128 registers (the narrow form is held to 96 for five waves per SIMD)
+template <bool WIDE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WIDE ? 4 : 5))) void crf_update_kernel(const CrfLattice Lg, const CrfLattice Lb, const PostDesc* __restrict__ imgs,
                                                          const float* __restrict__ vg, const float* __restrict__ vb,
                                                          const float* __restrict__ norm_g, const float* __restrict__ norm_b,
                                                          const float* __restrict__ unary, float* __restrict__ Q, float w_g,
@@ -763,7 +770,86 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void c
                 }
             }
             __syncthreads();
-            if (tid < TP * im.G) {                                      // one softmax per (pixel, channel group)
+            if (WIDE && K >= CRF_WAVE_SOFTMAX_K) {                       // (per image: the rows of a batch differ in width)
+                // Wide rows (round 6): the softmax of a tile's rows by WAVE, not by thread.  With one thread per (pixel, group) a
+                // 32-pixel tile of 2 x 150 channels keeps ONE wave busy for ~6000 dependent instructions per lane (150 exponentials
+                // in a row) while the other three idle.  Here each wave owns RW = TP * G / 4 rows and works through them without any
+                // workgroup barrier: maxima and exponentials with the lanes over the CHANNELS of one row at a time (the maximum is
+                // order-independent, pnp_expf is a pure function), the sums -- the one order-dependent step, k = 0 .. K - 1 as
+                // densecrf's expAndNormalize adds them -- with one LANE PER ROW, sequentially, all rows of the wave at once; then the
+                // divisions with the lanes over the channels again.  Element by element the arithmetic of the thread-per-row form:
+                // bit-identical marginals and labels.  (Narrower rows keep that form: measured slower there, see CRF_WAVE_SOFTMAX_K.)  Cross-lane hand-over through LDS inside one wave needs no barrier: a wave's LDS
+                // operations execute in order.
+                const int lane = tid & 63, wave = tid >> 6;
+                const int R = TP * im.G, RW = R >> 2;                   // rows (pixel, group) of the tile / per wave: 4 .. 64
+                const int rbase = wave * RW;
+                auto row_ptr = [&](int rr) {                            // row rr of the tile: group-major like the thread form
+                    const int grp = rr / TP, px = rr - grp * TP;
+                    return tile + px * ldt + grp * im.Kg;
+                };
+                float s_mine = 0.f;                                     // lane j < RW: sum of row rbase + j
+                // pass 1: per row, maximum (NaN if any NaN) and exponentials, lanes over channels; two rows at a time (RW is even), so
+                // that one row's shuffle chain runs under the other's loads and exponentials
+                for (int j = 0; j < RW; j += 2) {
+                    float* const row0 = row_ptr(rbase + j);
+                    float* const row1 = row_ptr(rbase + j + 1);
+                    float m0 = -INFINITY, m1 = -INFINITY;
+                    bool nan0 = false, nan1 = false;
+                    for (int k = lane; k < K; k += 64) {
+                        const float v0 = row0[k], v1 = row1[k];
+                        nan0 |= v0 != v0;
+                        nan1 |= v1 != v1;
+                        m0 = v0 > m0 ? v0 : m0;
+                        m1 = v1 > m1 ? v1 : m1;
+                    }
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) {
+                        const float a0 = __shfl_xor(m0, o, 64), a1 = __shfl_xor(m1, o, 64);
+                        m0 = a0 > m0 ? a0 : m0;
+                        m1 = a1 > m1 ? a1 : m1;
+                    }
+                    if (__any(nan0)) m0 = __builtin_nanf("");
+                    if (__any(nan1)) m1 = __builtin_nanf("");
+                    for (int k = lane; k < K; k += 64) {
+                        const float e0 = pnp_expf(__fsub_rn(row0[k], m0)), e1 = pnp_expf(__fsub_rn(row1[k], m1));
+                        row0[k] = e0;
+                        row1[k] = e1;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // pass 2: sums in channel order, one lane per row
+                if (lane < RW) {
+                    const float* row = row_ptr(rbase + lane);
+                    float sm = 0.f;
+                    for (int k = 0; k < K; k++) sm = __fadd_rn(sm, row[k]);
+                    s_mine = sm;
+                }
+                // pass 3: divisions, lanes over channels
+                for (int j = 0; j < RW; j++) {
+                    float* row = row_ptr(rbase + j);
+                    const float sm = __shfl(s_mine, j, 64);
+                    for (int k = lane; k < K; k += 64) row[k] = __fdiv_rn(row[k], sm);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane < RW) {
+                    const int rr = rbase + lane, grp = rr / TP, px = rr - grp * TP;
+                    float* row = tile + px * ldt + grp * im.Kg;
+                    if (lout.lab[grp]) {                                // last iteration: first maximum, NaN counts as maximum
+                        int best = 0;
+                        float bv = row[0];
+                        for (int k = 1; k < K; k++) {
+                            const float v = row[k];
+                            if (bv == bv && (v > bv || v != v)) {
+                                best = k;
+                                bv = v;
+                            }
+                        }
+                        if (inside(px)) lout.lab[grp][lout.label_off[b] + pixel_of(px)] = (uint8_t)lout.lut[b * lout.lut_stride + best];
+                    }
+                    if (grp == im.G - 1)                                // pad floats behind the last group stay zero
+                        for (int k = im.G * im.Kg; k < Kp; k++) tile[px * ldt + k] = 0.f;
+                }
+            } else if (tid < TP * im.G) {                               // one softmax per (pixel, channel group)
                 const int grp = tid / TP, px = tid - grp * TP;
                 const int p = pixel_of(px);
                 {
@@ -1111,33 +1197,38 @@ int crf_update(const CrfLattice& Lg, const CrfLattice& Lb, const PostDesc* d_img
 #endif
     if (tp < 4) return PNP_ERR_ARG;
     const size_t smem = tp * per_pixel;
+    const bool wide = max_kp / (groups > 0 ? groups : 1) >= CRF_WAVE_SOFTMAX_K;      // some image of the batch may have such rows
+    const void* const kern = wide ? reinterpret_cast<const void*>(crf_update_kernel<true>) : reinterpret_cast<const void*>(crf_update_kernel<false>);
     if (smem > 64 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(crf_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return PNP_ERR_HIP;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) return PNP_ERR_HIP;
     }
     (void)max_pixels;
     // (the occupancy depends on the tile's LDS bytes: queried per distinct size, a handful per process)
     static size_t grid_smem[16];
-    static int grid_dev[16], grid_nb[16], grid_n = 0;
+    static int grid_dev[16], grid_nb[16], grid_wide[16], grid_n = 0;
     static std::mutex grid_mu;                               // engines of different host threads / devices share the table
     int nbu = 0;
     {
         const int dev = current_device();
         std::lock_guard<std::mutex> lk(grid_mu);
         for (int i = 0; i < grid_n; i++)
-            if (grid_smem[i] == smem && grid_dev[i] == dev) nbu = grid_nb[i];
+            if (grid_smem[i] == smem && grid_dev[i] == dev && grid_wide[i] == (int)wide) nbu = grid_nb[i];
         if (!nbu) {
-            nbu = resident_grid(crf_update_kernel, 256, smem);
+            nbu = wide ? resident_grid(crf_update_kernel<true>, 256, smem) : resident_grid(crf_update_kernel<false>, 256, smem);
             if (grid_n < 16) {
                 grid_smem[grid_n] = smem;
                 grid_dev[grid_n] = dev;
+                grid_wide[grid_n] = (int)wide;
                 grid_nb[grid_n++] = nbu;
             }
         }
     }
-    hipLaunchKernelGGL(crf_update_kernel, dim3(nbu), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
-                       w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp, tile_w, labels);
+    if (wide)
+        hipLaunchKernelGGL(crf_update_kernel<true>, dim3(nbu), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
+                           w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp, tile_w, labels);
+    else
+        hipLaunchKernelGGL(crf_update_kernel<false>, dim3(nbu), dim3(256), smem, s, Lg, Lb, d_imgs, vg, vb, norm_g, norm_b, unary, Q,
+                           w_g, w_b, crf_alpha(2), crf_alpha(5), pairwise, img0, nimg, (int)tp, tile_w, labels);
     return ok();
 }
 
