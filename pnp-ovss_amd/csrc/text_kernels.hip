@@ -5,6 +5,8 @@
 //            blip_image_text_matching.py:238-249 (enc token, itm head), :399-404 (loss + backward).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -47,10 +49,39 @@ __global__ __launch_bounds__(NW * 64) void text_self_attn_kernel(const T* __rest
     const int h = blockIdx.x, b = blockIdx.y, nh = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t row0 = (size_t)b * L;
-    for (int i = tid; i < L * 64; i += NW * 64) {
-        const int j = i >> 6, d = i & 63;
-        ks[j * 65 + d] = to_f32(qkv[(row0 + j) * 3 * H + H + h * 64 + d]);
-        vs[j * 65 + d] = to_f32(qkv[(row0 + j) * 3 * H + 2 * H + h * 64 + d]);
+    if constexpr (std::is_same<T, float>::value) {
+        // K / V rows in 16-byte pieces, four of each in flight per thread (round 6: with one 4-byte load per array and trip the
+        // staging of 2 x L x 64 floats was ~40 dependent round trips to L2 -- most of the kernel at L = 85 ... 155)
+        const int npc = L * 16;                              // 16-byte pieces per array
+        for (int i0 = tid; i0 < npc; i0 += 4 * NW * 64) {
+            f32x4 kv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * NW * 64;
+                const int j = (i < npc ? i : npc - 1) >> 4, c4 = (i & 15) * 4;
+                const float* src = reinterpret_cast<const float*>(qkv) + (row0 + j) * 3 * H + H + h * 64 + c4;
+                kv[u] = *reinterpret_cast<const f32x4*>(src);
+                vv[u] = *reinterpret_cast<const f32x4*>(src + H);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * NW * 64;
+                if (i < npc) {
+                    const int j = i >> 4, c4 = (i & 15) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        ks[j * 65 + c4 + e] = kv[u][e];
+                        vs[j * 65 + c4 + e] = vv[u][e];
+                    }
+                }
+            }
+        }
+    } else {
+        for (int i = tid; i < L * 64; i += NW * 64) {
+            const int j = i >> 6, d = i & 63;
+            ks[j * 65 + d] = to_f32(qkv[(row0 + j) * 3 * H + H + h * 64 + d]);
+            vs[j * 65 + d] = to_f32(qkv[(row0 + j) * 3 * H + 2 * H + h * 64 + d]);
+        }
     }
     for (int j = tid; j < L; j += NW * 64) madd[j] = (1.0f - (float)mask[(size_t)b * ld_mask + j]) * -10000.0f;
     __syncthreads();
@@ -68,7 +99,15 @@ __global__ __launch_bounds__(NW * 64) void text_self_attn_kernel(const T* __rest
             const int j = lane + c * 64;
             float acc = 0.f;
             if (j < L) {
-                for (int d = 0; d < 64; d++) acc += myq[d] * ks[j * 65 + d];
+                // four partial sums (d mod 4): the kernel runs one to three waves per SIMD and was waiting on ONE dependent fma
+                // chain of 64 links per score (round 6)
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int d = 0; d < 64; d += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a4[u] += myq[d + u] * ks[j * 65 + d + u];
+                }
+                acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
                 acc = acc * 0.125f + madd[j];
             } else {
                 acc = -INFINITY;
@@ -95,8 +134,14 @@ __global__ __launch_bounds__(NW * 64) void text_self_attn_kernel(const T* __rest
             }
         }
         __builtin_amdgcn_wave_barrier();
-        float o = 0.f;
-        for (int j = 0; j < L; j++) o += myp[j] * vs[j * 65 + lane];
+        float o4[4] = {0.f, 0.f, 0.f, 0.f};                   // likewise: four partial sums over the keys (j mod 4)
+        int j = 0;
+        for (; j + 4 <= L; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) o4[u] += myp[j + u] * vs[(j + u) * 65 + lane];
+        }
+        for (; j < L; j++) o4[j & 3] += myp[j] * vs[j * 65 + lane];
+        const float o = (o4[0] + o4[1]) + (o4[2] + o4[3]);
         ctx[(row0 + i) * H + h * 64 + lane] = from_f32<T>(o);
         __builtin_amdgcn_wave_barrier();
     }
