@@ -187,7 +187,13 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
             const int j = lane + c * 64;
             float acc = 0.f;
             if (j < L) {
-                for (int d = 0; d < 64; d++) acc += myg[d] * bs[j * 65 + d];
+                float a4[4] = {0.f, 0.f, 0.f, 0.f};          // four partial sums, as in the forward kernel (round 6)
+#pragma unroll
+                for (int d = 0; d < 64; d += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a4[u] += myg[d + u] * bs[j * 65 + d + u];
+                }
+                acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
                 pv[c] = P[(size_t)i * L + j];
             } else {
                 pv[c] = 0.f;
@@ -206,8 +212,14 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
             }
         }
         __builtin_amdgcn_wave_barrier();
-        float o = 0.f;
-        for (int j = 0; j < L; j++) o += myp[j] * as[j * 65 + lane];
+        float o4[4] = {0.f, 0.f, 0.f, 0.f};
+        int j = 0;
+        for (; j + 4 <= L; j += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) o4[u] += myp[j + u] * as[(j + u) * 65 + lane];
+        }
+        for (; j < L; j++) o4[j & 3] += myp[j] * as[j * 65 + lane];
+        const float o = (o4[0] + o4[1]) + (o4[2] + o4[3]);
         dqkv[(row0 + i) * 3 * H + h * 64 + lane] = from_f32<T>(o * 0.125f);
         __builtin_amdgcn_wave_barrier();
     }
@@ -223,13 +235,26 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
     __threadfence_block();
     __syncthreads();
     for (int j = wave + 4 * blockIdx.z; j < L; j += 4 * gridDim.z) {
-        float dk = 0.f, dv = 0.f;
-        for (int i = 0; i < L; i++) {
-            const float ds = dS[(size_t)i * L + j];
-            const float p = P[(size_t)i * L + j];
-            dk += ds * as[i * 65 + lane];
-            dv += p * bs[i * 65 + lane];
+        float k4[4] = {0.f, 0.f, 0.f, 0.f}, v4[4] = {0.f, 0.f, 0.f, 0.f};
+        int i = 0;
+        for (; i + 4 <= L; i += 4) {
+            float ds[4], pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                ds[u] = dS[(size_t)(i + u) * L + j];
+                pp[u] = P[(size_t)(i + u) * L + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                k4[u] += ds[u] * as[(i + u) * 65 + lane];
+                v4[u] += pp[u] * bs[(i + u) * 65 + lane];
+            }
         }
+        for (; i < L; i++) {
+            k4[i & 3] += dS[(size_t)i * L + j] * as[i * 65 + lane];
+            v4[i & 3] += P[(size_t)i * L + j] * bs[i * 65 + lane];
+        }
+        const float dk = (k4[0] + k4[1]) + (k4[2] + k4[3]), dv = (v4[0] + v4[1]) + (v4[2] + v4[3]);
         dqkv[(row0 + j) * 3 * H + H + h * 64 + lane] = from_f32<T>(dk * 0.125f);
         dqkv[(row0 + j) * 3 * H + 2 * H + h * 64 + lane] = from_f32<T>(dv);
     }
@@ -240,7 +265,7 @@ __global__ __launch_bounds__(256) void text_self_attn_bwd_kernel(const T* __rest
 // PnP.py:271,318, B/blip_image_text_matching.py:48,234).  Two fp32 [L][65] arrays no longer fit the 160 KB of LDS, so the same
 // one-wave-per-row scheme runs in PHASES over ONE staged array; what a later phase needs of an earlier one goes through global
 // memory -- the probabilities through the layer's stash (or a scratch of the same shape), dS through the scratch the short
-// kernel uses too.  Same arithmetic and summation order per row as the short kernels.
+// kernel uses too.  Same arithmetic per row as the short kernels (which, since round 6, add their dot products in four partial sums).
 constexpr int TXT_LONG_L = 512;
 constexpr int TXT_LONG_CH = TXT_LONG_L / 64;
 
