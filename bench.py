@@ -629,7 +629,7 @@ def run_rank(a):
         the guide's gfx950 correction; TCC_HIT + TCC_MISS).  Only the configs' own image noise has such a pass."""
         if noise != NOISE:
             return None
-        inside = lambda k: ("crf_splat_kernel" in k) or k.startswith("crf_blur4") or k.startswith("crf_update")
+        inside = lambda k: ("crf_splat_kernel" in k) or ("crf_blur4" in k) or ("crf_update" in k)
         for tag in ("r06", "r05"):
             tf = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json" if name == "voc" else f"{tag}_{name}_crf_traffic.json")
             if not os.path.exists(tf):
