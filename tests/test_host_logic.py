@@ -420,3 +420,27 @@ def test_merge_plan_on_real_tokenizer_splits_of_dataset_class_names():
             assert plan[c][0] == list(range(p, q))
             n_split_words += q - p > 1
     assert n_split_words >= 140                                   # the fixture really is about split words (149 of 267)
+
+
+def test_inject_outliers_is_function_preserving_on_the_oracle():
+    """synth.inject_outliers (the weights of tests/golden/droploop_large_outliers.npz): a power-of-two gain with the consuming weights
+    scaled back leaves the oracle's maps BIT-identical (scaling by 2^k is exact in binary floating point: a control, not a stress);
+    jittered gains change them only in the last bits; without compensation the model is a different one."""
+    from pnp_ovss import config as C, synth
+    from oracle import blip_itm_np as OM
+    cfg = C.blip_itm_small(64)
+    W = synth.synth_state_dict(cfg, 3)
+    _, imgs = synth.synth_images(2, cfg.img_size, seed=5)
+    ids, mask = synth.synth_tokens(cfg, [4, 2], seed=1)
+    m0, l0, _ = OM.compute_gradcam(W, cfg, imgs, ids, mask, layers=[7])
+    m1, l1, _ = OM.compute_gradcam(synth.inject_outliers(W, cfg, 16.0), cfg, imgs, ids, mask, layers=[7])
+    assert np.array_equal(m1[7], m0[7]) and np.array_equal(l1, l0)
+    m2, l2, _ = OM.compute_gradcam(synth.inject_outliers(W, cfg, 16.0, jitter=0.5), cfg, imgs, ids, mask, layers=[7])
+    assert 0 < np.abs(m2[7] - m0[7]).max() < 1e-5 * np.abs(m0[7]).max() + 1e-6
+    m3, _, _ = OM.compute_gradcam(synth.inject_outliers(W, cfg, 8.0, jitter=0.5, compensate=False), cfg, imgs, ids, mask, layers=[7])
+    assert np.abs(m3[7] - m0[7]).max() > 1e-3
+    # the three variants of the fixture draw different channels / gains (same seed: reparam64 would be reparam16 x 4, bit-identical)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "droploop_large_outliers.npz"), allow_pickle=False)
+    v = json.loads(str(g["variants"]))
+    assert v["reparam16"].get("seed", 99) != v["reparam64"].get("seed", 99)
+    assert not np.array_equal(g["reparam16_agg"], g["reparam64_agg"])
