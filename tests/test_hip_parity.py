@@ -1206,6 +1206,30 @@ def test_end_to_end_labels_vs_reference_run(fname, mode_):
                   f"largest relative gap between the two best channels at such a pixel {gap:.2e}")
             assert bad == 0, (name, mode, bad, gap)
             assert flips <= 0.005 * total, (name, mode, flips)
+            if not large:
+                # The same statement DERIVED instead of calibrated (small geometry: the fixture holds the reference's own maps in
+                # front of `postprocess`, so its final maps are the oracle's scipy-pinned blur of them): with delta = the largest
+                # deviation of our final maps from the reference's final maps IN THIS RUN, an argmax can differ only where the
+                # reference's own two best channels are within 2 delta of each other (a_dev wins on our maps, a_ref on theirs:
+                # R[a_ref] - R[a_dev] <= |D - R|(a_ref) + |D - R|(a_dev)) -- checked pixel by pixel -- and delta itself is bounded:
+                # the final maps are min-max normalised to [0, 1]; north_star's 1e-4 is on the saliency maps in front of the
+                # normalisation's 1 / (max - min)
+                br = 0 if name == "1drop" else 1
+                for i in range(B):
+                    pre = g[f"prepost_blur_{br * B + i}"]
+                    R = np.stack([OP.blurring(pre[c], sizes[i]) for c in range(pre.shape[0])]) if mode else pre
+                    D = maps[i]
+                    if R.shape != D.shape or not (np.isfinite(R).all() and np.isfinite(D).all()) or R.shape[0] < 2:
+                        continue                      # a constant channel (0 / 0 in `blurring`): NaN maps, labels compared above
+                    delta = float(np.abs(D - R).max())
+                    assert delta < (1.5e-4 if mode_ == "f32" else 5e-4), (name, mode, i, delta)    # measured on MI355X: <= 5.2e-5 / 1.5e-4
+                    a_dev, a_ref = D.argmax(0), R.argmax(0)
+                    fl = a_dev != a_ref
+                    if fl.any():
+                        margin = np.take_along_axis(R, a_ref[None], 0)[0] - np.take_along_axis(R, a_dev[None], 0)[0]
+                        assert float(margin[fl].max()) <= 2 * delta, (name, mode, i, float(margin[fl].max()), delta)
+                    print(f"[e2e derived {fname} {mode_} {name} {mode} image {i}] final-map deviation {delta:.2e}, "
+                          f"{int(fl.sum())} argmax flips, all inside the reference's own 2-delta ties")
     if large:            # (the oracle's BLIP-large forward takes minutes on the host; blur + CRF at full size vs the oracle
         return           #  is test_densecrf_full_size_bit_exact_vs_oracle)
     # blur + CRF: device path vs the oracle run on the same inputs end to end
