@@ -264,7 +264,9 @@ int pnp_profile_read_stage(pnp_engine* e, int32_t stage, int64_t* launches, doub
  *   "streamk": the stream-K tail of the persistent split-bf16 GEMM (the ViT Linears of B/vit.py:45-51, 93-117 at M = B * N rows):
  *              0 = whole tiles only, 1 (default) = the last partial round of tiles is cut along K over all CUs when the cost
  *              model says it pays, 2 = whenever a launch has a partial last round.  Results are deterministic in every
- *              mode (fixed-order fix-up, no atomics) and differ between modes only by fp32 summation order. */
+ *              mode (fixed-order fix-up, no atomics) and differ between modes only by fp32 summation order.  Launches on a
+ *              stream that is being captured into a hipGraph always take whole tiles (the tail's one-launch-at-a-time event
+ *              chain reaches across streams). */
 int pnp_set_tuning(const char* key, int32_t value);
 /* Launches that used the engine's (e = NULL: the op-level entry points') stream-K workspace, and the give-up word of its
  * bounded spins (0 = no owner ever gave up waiting for a partial tile; anything else is a bug report).  Synchronises. */

@@ -697,7 +697,11 @@ static int launch_x3(GemmArgs g, hipStream_t s) {
         if (tail > 0) {
             const int upw = (int)(((long)tail * nk2 + cap - 1) / cap);
             const int np = (nk2 - 1 + upw - 1) / upw;                    // parts in front of the last one of a tile, at most
-            if (mode == 2 || streamk_pays(tail, cap, nk2, upw, np)) {
+            // (a stream that is being captured into a graph keeps whole tiles: the event chain below reaches across streams, which
+            // a capture must not, and one-launch-at-a-time cannot be promised for replays)
+            hipStreamCaptureStatus cap_st = hipStreamCaptureStatusNone;
+            const bool capturing = hipStreamIsCapturing(s, &cap_st) == hipSuccess && cap_st != hipStreamCaptureStatusNone;
+            if (!capturing && (mode == 2 || streamk_pays(tail, cap, nk2, upw, np))) {
                 if (lds_opt_in(opted_sk, reinterpret_cast<const void*>(gemm_nt_x3_kernel<EPI, true>), kWideSmem) != PNP_OK) return PNP_ERR_HIP;
                 g.sk_part = ws->part;
                 g.sk_flag = ws->flag;

@@ -353,6 +353,41 @@ def test_gemm_stream_k_is_deterministic_and_timing_independent(streamk_forced):
     assert hip.streamk_status_ops()[1] == 0
 
 
+def test_gemm_on_a_capturing_stream_keeps_whole_tiles(streamk_forced):
+    """A launch recorded into a hipGraph must not take the stream-K tail (its one-launch-at-a-time event chain reaches across
+    streams, which a capture must not): captured with the tail forced on, the launch takes whole tiles, and the replayed graph
+    reproduces the eager whole-tile result bit for bit."""
+    hip = streamk_forced
+    lib = hip.load_library()
+    M, N, K = 5304, 1024, 4096
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) * 0.05).cuda()
+    (Ah, Al), (Bh, Bl) = _split(A), _split(B)
+    bias = torch.randn(N, generator=g).cuda()
+    p = lambda t: t.data_ptr()
+    out = torch.zeros(M, N, device="cuda")
+
+    def run():
+        assert lib.pnp_op_gemm_x3(p(Ah), p(Al), K, p(Bh), p(Bl), K, M, N, K, p(bias), 0, None, 0, p(out), N, None, None, 0, 0, 0, 0,
+                                  torch.cuda.current_stream().cuda_stream) == 0
+    run()                                                     # eager, stream-K (forced): warms the workspace up
+    torch.cuda.synchronize()
+    n0 = hip.streamk_status_ops()[0]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    assert hip.streamk_status_ops()[0] == n0, "a captured launch took the stream-K path"
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    got = out.clone()
+    hip.set_tuning("streamk", 0)
+    run()
+    torch.cuda.synchronize()
+    assert torch.equal(got, out)
+
+
 def test_gemm_stream_k_launches_from_two_streams_do_not_meet(streamk_forced):
     """Two streams issue stream-K launches back to back (the engines of a multi-pipeline run do): the launcher chains them through
     an event per device -- one launch with spinning owners in flight at a time, so no launch can sit on the CUs another's
