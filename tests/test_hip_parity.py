@@ -1474,6 +1474,31 @@ def test_drop_loop_large_with_outlier_channels_vs_reference(mode, variant):
         assert _nerr(tag + " agg", gota[b, sl], ra[b, sl]) < tol
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_drop_loop_is_graph_capturable(mode):
+    """include/pnp_hip.h: "the hot path calls allocate nothing and never synchronise the device (hipGraph-capturable)".  The whole
+    four-iteration drop loop (ViT + text forward, analytic backward, gather, pick, patch drop: a few thousand launches) recorded
+    into a graph on torch's capture stream and replayed reproduces the eager run bit for bit."""
+    cfg = C.blip_itm_small(128)
+    _, imgs = synth.synth_images(3, cfg.img_size, seed=6)
+    ids, mask = synth.synth_tokens(cfg, [5, 2, 1], seed=2)
+    L = int(mask.sum(1).max())
+    e = _engine(cfg, 4, mode, max_batch=3, max_text_len=16)
+    di, dd, dm = _dev(imgs), _dev(ids), _dev(mask)
+    g0, agg, picks, _ = e.drop_loop(di, dd, dm, L, 9, 4)
+    torch.cuda.synchronize()
+    ref = (g0.clone(), agg.clone(), picks.clone())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = e.drop_loop(di, dd, dm, L, 9, 4)
+    for t in out[:3]:
+        t.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(out[:3], ref):
+        assert torch.equal(a, b)
+
+
 def test_bf16x3_picks_equal_f32_at_blip_large_batch35():
     """Pick parity of the benchmarked mode at full model size AND at the bench's batch (B = 35: the wide GEMM's multi-tile
     launches, 732 / 976 tiles on 256 CUs, are part of what is compared): 35 images through BLIP-ITM-large 336^2, drop_iter 4,
