@@ -719,6 +719,13 @@ def run_rank(a):
                                      "the whole path over one batch; the engines share one weight copy", "one_batch_at_a_time": seq,
                              "engine_device_bytes": [int(e.allocated_bytes()) for e in wl.engines[:max(P, 1)]]},
                "roofline": roof, "crf": roofline_crf(crf, steps, ppp, wl.name, noise)}
+        if wl.dtype == "bf16x3":
+            # the stream-K tail of the split-bf16 GEMM (csrc/gemm_x3.hip): launches that took it, and the give-up word of its bounded
+            # spins -- an owner that gave up waiting for a partial tile produced garbage, so anything but 0 fails the run loudly
+            sk = [e.streamk_status() for e in wl.engines[:max(P, 1)]]
+            rec["streamk"] = {"launches": int(sum(n for n, _ in sk)), "gave_up": int(max(t for _, t in sk))}
+            if rec["streamk"]["gave_up"]:
+                raise SystemExit(f"bench.py: a stream-K owner gave up waiting for a partial tile (word {rec['streamk']['gave_up']}): results invalid")
         rec["roofline"]["measured_in"] = rec["crf"]["measured_in"] = (
             "one-batch-at-a-time pass of the same workload in this run (%d timed steps, %.1f ms per step)" % (steps, seq["ms_per_step"]))
         return rec, state
@@ -762,7 +769,7 @@ def run_rank(a):
                        "f32": "the reference's arithmetic (exact fp32 MFMA)",
                        "bf16": "does NOT reproduce the reference's patch picks"}[a.dtype],
             "config": workload_cfg(wl, a.noise),
-            "pipelines": head["pipelines"], "roofline": head["roofline"], "crf": head["crf"],
+            "pipelines": head["pipelines"], "roofline": head["roofline"], "crf": head["crf"], "streamk": head.get("streamk"),
             "collectives": dict(weights_for(wl.cfg)[2], hist_allreduce_and_label_gather_ms=1e3 * t_reduce,
                                 per_rank_images_per_sec=per_rank,
                                 hist_ndrop_total=int(state["histn"].sum().item()),       # all-reduced: pixels counted by ALL ranks
