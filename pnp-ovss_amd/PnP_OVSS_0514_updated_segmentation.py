@@ -330,6 +330,10 @@ def main(rank, world_size, args):
         ds.total_hist += finish(pending)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t_loop
+    for m_, _ in replicas:                      # split-bf16 engines: the stream-K tail's bounded spins must never have given up
+        st = getattr(m_.engine, "streamk_status", None)
+        if st is not None and st()[1]:
+            raise RuntimeError(f"a stream-K owner gave up waiting for a partial tile (word {st()[1]}): results invalid")
     dev = torch.device("cuda", dev_idx)
     total = torch.from_numpy(ds.total_hist).to(dev)
     count = torch.tensor([n_img], device=dev, dtype=torch.int64)
